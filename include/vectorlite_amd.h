@@ -1,0 +1,165 @@
+/*
+ * vectorlite_amd.h -- C ABI of the MI355X-native distance-scan engine.
+ *
+ * Drop-in boundary for ONE path of mmailhos/vectorlite v0.1.5: the distance
+ * scan + top-k behind `trait VectorIndex` (src/lib.rs:224-245), i.e. what
+ * `FlatIndex` (src/index/flat.rs:60-135) and the distance callbacks / score
+ * post-processing of `HNSWIndex` (src/index/hnsw.rs:113-174, :415-496) do.
+ * A Rust `impl VectorIndex for GpuFlatIndex` binds these symbols through
+ * `extern "C"`; text/metadata stay on the Rust side keyed
+ * by id -- this library returns (id, score) pairs only.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; the caller owns every in/out buffer and the
+ *    library keeps no pointer past the call;
+ *  - every function returns a vl_status; no C++ exception crosses the boundary;
+ *  - vectors, queries and scores are f64 like the reference
+ *    (src/lib.rs:168,198,232); ids are arbitrary u64;
+ *  - search calls are re-entrant and may run concurrently from many threads on
+ *    one handle (the reference searches under RwLock::read, src/client.rs:398);
+ *    add/delete take the handle exclusively (RwLock::write, src/client.rs:333,383);
+ *  - there is NO CPU fallback: without a usable HIP device every compute entry
+ *    point returns VL_ERR_DEVICE.
+ */
+#ifndef VECTORLITE_AMD_H
+#define VECTORLITE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enum SimilarityMetric, declaration order (src/lib.rs:363-378) */
+typedef enum vl_metric {
+    VL_COSINE = 0,     /* cosine_similarity     src/lib.rs:425-444 */
+    VL_EUCLIDEAN = 1,  /* euclidean_similarity  src/lib.rs:476-489 */
+    VL_MANHATTAN = 2,  /* manhattan_similarity  src/lib.rs:521-532 */
+    VL_DOTPRODUCT = 3  /* dot_product           src/lib.rs:565-572 */
+} vl_metric;
+
+typedef enum vl_status {
+    VL_OK = 0,
+    VL_ERR_DIM_MISMATCH = 1,    /* DimensionMismatch{expected,actual} src/errors.rs:18; "Vector dimension mismatch" src/index/flat.rs:84 */
+    VL_ERR_DUP_ID = 2,          /* "Vector ID {} already exists"      src/index/flat.rs:87 */
+    VL_ERR_NOT_FOUND = 3,       /* "Vector ID {} does not exist"      src/index/hnsw.rs:401-403; get_vector -> None */
+    VL_ERR_METRIC_MISMATCH = 4, /* MetricMismatch{requested,index}    src/errors.rs:42, src/index/hnsw.rs:425-430 */
+    VL_ERR_NAN_SCORE = 5,       /* stands in for the partial_cmp().unwrap() panic, src/index/flat.rs:116 */
+    VL_ERR_DEVICE = 6,          /* HIP runtime / kernel failure, or no device */
+    VL_ERR_OOM = 7,             /* host or device allocation failed */
+    VL_ERR_INVALID_ARG = 8      /* null pointer, unknown metric, ... */
+} vl_status;
+
+/* Which search pipeline produced the last result on this thread (diagnostics). */
+typedef enum vl_path {
+    VL_PATH_NONE = 0,
+    VL_PATH_FAST = 1,       /* f32 slab scan -> top-64 candidates -> exact f64 rescoring, bound check passed */
+    VL_PATH_EXACT_SELECT = 2, /* full f64 scan in reference arithmetic + exact top-k select (k <= 64) */
+    VL_PATH_EXACT_SORT = 3    /* full f64 scan + device-wide sort (any k) */
+} vl_path;
+
+typedef struct vl_index vl_index; /* opaque; Send + Sync */
+
+/* ---- lifecycle ---------------------------------------------------------- */
+
+/* FlatIndex::new(dim, Vec::new())  (src/index/flat.rs:68-73) on HIP device `device`. */
+int vl_flat_create(uint64_t dim, int device, vl_index **out);
+
+/* FlatIndex::new(dim, data) with n rows: like the reference it validates
+ * nothing (duplicate ids are kept).  `values` is [n, dim] row-major f64 on the host. */
+int vl_flat_from_rows(uint64_t dim, const uint64_t *ids, const double *values, uint64_t n, int device,
+                      vl_index **out);
+
+/* #[derive(Clone)] (src/index/flat.rs:59; persistence clones the index, src/persistence.rs:118). */
+int vl_index_clone(const vl_index *h, vl_index **out);
+
+void vl_index_destroy(vl_index *h);
+
+/* Pre-size device storage for `n_rows` (optional; storage grows geometrically otherwise). */
+int vl_index_reserve(vl_index *h, uint64_t n_rows);
+
+/* ---- trait VectorIndex (src/lib.rs:224-245) ------------------------------- */
+
+/* add(Vector): VL_ERR_DIM_MISMATCH if len != dim, VL_ERR_DUP_ID if id exists (src/index/flat.rs:82-91). */
+int vl_index_add(vl_index *h, uint64_t id, const double *values, uint64_t len);
+
+/* n x add() in order, one device pass.  validate != 0: stop at the first row whose id
+ * already exists (rows before it are kept, like n sequential adds) and return VL_ERR_DUP_ID;
+ * validate == 0: FlatIndex::new semantics (no checks).  values_on_device != 0: `values`
+ * is a device pointer on the index's device ([n, dim] f64). */
+int vl_index_add_bulk(vl_index *h, const uint64_t *ids, const double *values, uint64_t n, int validate,
+                      int values_on_device);
+
+/* delete(id): removes every row with that id, order-preserving; VL_OK even when
+ * the id is absent (src/index/flat.rs:93-96). */
+int vl_index_delete(vl_index *h, uint64_t id);
+
+/* search(query, k, metric) (src/index/flat.rs:98-119): writes min(k, len) results, best first,
+ * ties in insertion order.  out_ids/out_scores must hold min(k, len) entries.
+ * Empty index: any q_len is accepted and *out_n = 0.  Otherwise q_len != dim ->
+ * VL_ERR_DIM_MISMATCH (vl_last_dim_mismatch gives expected/actual). */
+int vl_index_search(const vl_index *h, const double *query, uint64_t q_len, uint64_t k, int metric,
+                    uint64_t *out_ids, double *out_scores, uint64_t *out_n);
+
+/* NEW capability (the reference has no batch entry, src/lib.rs:224-245): nq independent
+ * searches, each with exactly vl_index_search's result.  queries is [nq, q_len];
+ * out_ids/out_scores are [nq, k] (row stride k), out_n is [nq]. */
+int vl_index_search_batch(const vl_index *h, const double *queries, uint64_t nq, uint64_t q_len, uint64_t k,
+                          int metric, uint64_t *out_ids, double *out_scores, uint64_t *out_n);
+
+uint64_t vl_index_len(const vl_index *h);      /* len()       src/index/flat.rs:121-123 */
+int vl_index_is_empty(const vl_index *h);      /* is_empty()  src/index/flat.rs:125-127 */
+uint64_t vl_index_dimension(const vl_index *h);/* dimension() src/index/flat.rs:133-135 */
+
+/* get_vector(id) (src/index/flat.rs:129-131): first row with that id -> out[dim];
+ * VL_ERR_NOT_FOUND stands for None. */
+int vl_index_get_vector(const vl_index *h, uint64_t id, double *out_values);
+
+/* max_id() (src/index/flat.rs:76-78): VL_ERR_NOT_FOUND stands for None (empty index). */
+int vl_index_max_id(const vl_index *h, uint64_t *out_id);
+
+/* Rows in storage order, for Serialize (src/index/flat.rs:59): ids[len], values[len, dim]. */
+int vl_index_export(const vl_index *h, uint64_t *out_ids, double *out_values);
+
+/* ---- multi-GPU row shards (no reference counterpart) ---------------------- */
+
+/* Like vl_index_search but returns storage POSITIONS (0-based, this shard) instead of ids,
+ * so that a caller holding contiguous row shards can merge per-shard top-k by
+ * (score desc, shard offset + position asc) -- the reference's stable order. */
+int vl_index_search_positions(const vl_index *h, const double *query, uint64_t q_len, uint64_t k, int metric,
+                              uint64_t *out_pos, uint64_t *out_ids, double *out_scores, uint64_t *out_n);
+
+/* ---- HNSW distance callbacks (src/index/hnsw.rs:113-174) ------------------ */
+
+/* For each of the m stored rows at `positions`, Metric::distance(query, row) -> u64
+ * (trunc(dist * 1000), Rust `as u64` saturation), computed on the device in the
+ * reference's f64 operation order. */
+int vl_index_hnsw_distances(const vl_index *h, const double *query, uint64_t q_len, int metric,
+                            const uint64_t *positions, uint64_t m, uint64_t *out_dist);
+
+/* convert_distance_to_similarity(d_u64 as f64 / 1000.0, metric) (src/index/hnsw.rs:51-75, :478-479). */
+double vl_hnsw_score(uint64_t d_u64, int metric);
+
+/* ---- diagnostics ---------------------------------------------------------- */
+
+const char *vl_last_error(void);                                 /* thread-local message */
+void vl_last_dim_mismatch(uint64_t *expected, uint64_t *actual); /* of the last VL_ERR_DIM_MISMATCH on this thread */
+int vl_last_path(void);                                          /* vl_path of the last search on this thread */
+
+/* Force every search onto an exact pipeline (testing): 0 = automatic, 2 / 3 = vl_path value. */
+int vl_index_force_path(vl_index *h, int path);
+
+/* Kernel timing with HIP events on the stream the scan kernel runs on.
+ * enable != 0 starts accumulating; vl_index_profile_read returns and clears the totals. */
+int vl_index_profile_enable(vl_index *h, int enable);
+int vl_index_profile_read(vl_index *h, uint64_t *n_scan_launches, double *scan_ms_total,
+                          uint64_t *scan_bytes_total);
+
+/* Library/version probe; also reports how many HIP devices are visible (0 -> no GPU). */
+int vl_runtime_info(int *n_devices, int *abi_version);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VECTORLITE_AMD_H */

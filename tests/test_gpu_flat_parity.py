@@ -1,0 +1,367 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the committed
+golden fixtures.  Bar: ids bit-exact, scores bit-exact (==), far inside north_star's 1e-5.
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+M = {"cosine": 0, "euclidean": 1, "manhattan": 2, "dotproduct": 3}
+
+
+@pytest.fixture(scope="module")
+def V():
+    import vectorlite_amd as V
+    n_dev, _ = V.runtime_info()
+    assert n_dev > 0, "GPU tests need a HIP device"
+    return V
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+def unit_rows(rng, n, dim):
+    """i.i.d. N(0,1), L2-normalised in f64 (mirrors src/embeddings.rs:173-179)."""
+    x = rng.standard_normal((n, dim))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x
+
+
+def permuted_ids(n):
+    return (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(12345)) % np.uint64(2 ** 40)
+
+
+def assert_same(V, gpu, ref, ctx):
+    gi, gs = gpu
+    ri, rs = ref
+    assert gi.tolist() == ri.tolist(), ("ids", ctx, V.last_path())
+    # bit-exact scores, NaN-free; +-0.0 compared by value like partial_cmp
+    assert gs.tolist() == rs.tolist(), ("scores", ctx, V.last_path())
+
+
+# ---------------------------------------------------------------------------------------------
+# golden fixtures (the reference's own tests)
+# ---------------------------------------------------------------------------------------------
+def test_reference_flat_kats(V, kats):
+    seen = {}
+    for kat in kats["flat_kats"]:
+        data = [V.Vector(id=i, values=r, text="test") for i, r in zip(kat["ids"], kat["rows"])]
+        idx = V.FlatIndex(kat["dim"], data)
+        res = idx.search(kat["query"], kat["k"], M[kat["metric"]])
+        seen[kat["src"]] = res
+        assert len(res) == kat["len"], kat["src"]
+        assert res[0].id == kat["first_id"], kat["src"]
+        assert res[0].text == "test"
+        if "first_score" in kat:
+            assert abs(res[0].score - kat["first_score"]) <= kat["tol"], kat["src"]
+        if "first_score_gt" in kat:
+            assert res[0].score > kat["first_score_gt"]
+        if kat.get("sorted_desc"):
+            assert all(res[i - 1].score >= res[i].score for i in range(1, len(res)))
+    for pair in kats["flat_pairs_differ"]:
+        assert seen[pair["a"]][0].score != seen[pair["b"]][0].score
+
+
+def test_reference_metric_kats_via_single_row_index(V, kats):
+    """calculate(a, b) is reachable as the score of a 1-row index holding `a` queried with `b`."""
+    for kat in kats["metric_kats"]:
+        idx = V.FlatIndex(len(kat["a"]), [V.Vector(id=7, values=kat["a"])])
+        res = idx.search(kat["b"], 1, M[kat["metric"]])
+        assert res[0].id == 7
+        assert abs(res[0].score - kat["expect"]) <= kat["tol"], kat["src"]
+
+
+def test_survey_9_6_values_bit_exact(V):
+    idx = V.FlatIndex(3, [V.Vector(1, [1, 0, 0]), V.Vector(2, [0, 1, 0]), V.Vector(3, [0, 0, 1])])
+    ids, sc = idx.search_arrays([1, 0, 0], 2, 0)
+    assert ids.tolist() == [1, 2] and sc.tolist() == [1.0, 0.0]
+    ids, sc = idx.search_arrays([1.1, 0.1, 0.1], 2, 0)
+    assert ids.tolist() == [1, 2]
+    assert sc[0] == pytest.approx(0.99183659813417546, abs=1e-15)
+    assert sc[1] == pytest.approx(0.090166963466743216, abs=1e-15)
+    idx = V.FlatIndex(2, [V.Vector(1, [1, 2]), V.Vector(2, [2, 1])])
+    assert idx.search_arrays([1, 2], 1, 0)[1][0] == 0.99999999999999978
+    assert idx.search_arrays([1, 2], 1, 3)[1][0] == 5.0
+
+
+# ---------------------------------------------------------------------------------------------
+# seeded random parity against the oracle
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dim", [1, 3, 4, 5, 33, 128, 384, 768, 100])
+def test_random_parity_all_metrics(V, O, dim):
+    rng = np.random.default_rng(1234 + dim)
+    for n in (1, 2, 63, 64, 65, 257, 1000):
+        rows = unit_rows(rng, n, dim)
+        ids = permuted_ids(n)
+        gpu = V.FlatIndex(dim)
+        gpu.add_rows(ids, rows, validate=False)
+        ref = O.FlatOracle(dim, ids, rows)
+        for qi in range(3):
+            q = unit_rows(rng, 1, dim)[0]
+            for name, m in M.items():
+                for k in (1, 10, 32):
+                    assert_same(V, gpu.search_arrays(q, k, m), ref.search(q, k, m), (dim, n, name, k))
+
+
+def test_fast_path_is_the_one_running(V, O):
+    rng = np.random.default_rng(99)
+    n, dim = 20000, 384
+    rows = unit_rows(rng, n, dim)
+    ids = permuted_ids(n)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    for qi in range(8):
+        q = unit_rows(rng, 1, dim)[0]
+        for name, m in M.items():
+            assert_same(V, gpu.search_arrays(q, 10, m), ref.search(q, 10, m), (name, qi))
+            assert V.last_path() == V.PATH_FAST, name
+
+
+def test_unnormalised_and_scaled_data(V, O):
+    rng = np.random.default_rng(5)
+    dim, n = 96, 3000
+    for scale in (1e-6, 1.0, 37.5, 1e6):
+        rows = rng.standard_normal((n, dim)) * scale * rng.uniform(0.1, 10.0, size=(n, 1))
+        ids = permuted_ids(n)
+        gpu = V.FlatIndex(dim)
+        gpu.add_rows(ids, rows, validate=False)
+        ref = O.FlatOracle(dim, ids, rows)
+        q = rng.standard_normal(dim) * scale
+        for name, m in M.items():
+            assert_same(V, gpu.search_arrays(q, 10, m), ref.search(q, 10, m), (scale, name))
+
+
+# ---------------------------------------------------------------------------------------------
+# ties, duplicates, zero rows: the stable (insertion-order) tie-break
+# ---------------------------------------------------------------------------------------------
+def test_all_rows_identical_mock_embedding_case(V, O):
+    """MockEmbeddingFunction stores vec![1.0; dim] for every text (src/client.rs:504-523)."""
+    dim, n = 384, 500
+    rows = np.ones((n, dim))
+    ids = np.arange(n, dtype=np.uint64)[::-1].copy()  # ids descending: position, not id, breaks ties
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows)
+    ref = O.FlatOracle(dim, ids, rows)
+    for name, m in M.items():
+        assert_same(V, gpu.search_arrays(np.ones(dim), 10, m), ref.search(np.ones(dim), 10, m), name)
+        assert V.last_path() in (V.PATH_EXACT_SELECT, V.PATH_EXACT_SORT)
+    assert gpu.search_arrays(np.ones(dim), 1, 0)[0].tolist() == [n - 1]  # first inserted row
+
+
+def test_duplicates_and_zero_rows(V, O):
+    rng = np.random.default_rng(11)
+    dim, n = 64, 4000
+    rows = unit_rows(rng, n, dim)
+    dup = rng.choice(n, size=n // 100, replace=False)
+    rows[dup] = rows[(dup + 7) % n]  # 1 % exact duplicates
+    rows[17] = 0.0  # zero row: cosine 0.0 branch (src/lib.rs:439-440)
+    rows[n - 1] = 0.0
+    ids = permuted_ids(n)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    for qi in range(6):
+        q = rows[dup[qi]] if qi < 3 else unit_rows(rng, 1, dim)[0]  # query equal to a duplicated row
+        for name, m in M.items():
+            for k in (1, 2, 10, 32):
+                assert_same(V, gpu.search_arrays(q, k, m), ref.search(q, k, m), (qi, name, k))
+    zq = np.zeros(dim)  # zero query: every cosine score is 0.0 -> pure insertion order
+    for name, m in M.items():
+        assert_same(V, gpu.search_arrays(zq, 10, m), ref.search(zq, 10, m), ("zero query", name))
+
+
+# ---------------------------------------------------------------------------------------------
+# k handling and the exact pipelines
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,dim", [(50, 8), (700, 48), (5000, 384)])
+def test_large_k_and_forced_exact_paths(V, O, n, dim):
+    rng = np.random.default_rng(n)
+    rows = unit_rows(rng, n, dim)
+    rows[n // 2] = rows[n // 3]
+    ids = permuted_ids(n)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    q = unit_rows(rng, 1, dim)[0]
+    for name, m in M.items():
+        for k in (0, 1, 33, 64, 65, 200, n, n + 1, 10 * n):
+            assert_same(V, gpu.search_arrays(q, k, m), ref.search(q, k, m), (name, k))
+        for path in (V.PATH_EXACT_SELECT, V.PATH_EXACT_SORT):
+            gpu.force_path(path)
+            for k in (1, 10, 64):
+                assert_same(V, gpu.search_arrays(q, k, m), ref.search(q, k, m), (name, k, path))
+                assert V.last_path() == path
+        gpu.force_path(0)
+
+
+def test_out_of_domain_rows_use_exact_path(V, O):
+    rng = np.random.default_rng(3)
+    dim, n = 32, 300
+    rows = unit_rows(rng, n, dim)
+    rows[5] *= 1e30   # beyond the f32 fast-path domain
+    rows[9] *= 1e-30
+    ids = permuted_ids(n)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    q = unit_rows(rng, 1, dim)[0]
+    for name, m in M.items():
+        assert_same(V, gpu.search_arrays(q, 10, m), ref.search(q, 10, m), name)
+        assert V.last_path() == V.PATH_EXACT_SELECT
+    gpu.delete(int(ids[5]))
+    gpu.delete(int(ids[9]))
+    ref.delete(int(ids[5]))
+    ref.delete(int(ids[9]))
+    assert_same(V, gpu.search_arrays(q, 10, 0), ref.search(q, 10, 0), "after delete")
+    assert V.last_path() == V.PATH_FAST
+    # a huge query also leaves the domain
+    assert_same(V, gpu.search_arrays(q * 1e200, 10, 0), ref.search(q * 1e200, 10, 0), "huge query")
+
+
+def test_nan_scores_map_to_the_panic(V, O):
+    idx = V.FlatIndex(2, [V.Vector(1, [1.0, 2.0]), V.Vector(2, [3.0, 4.0])])
+    with pytest.raises(V.NaNScore):
+        idx.search([float("nan"), 0.0], 1, 3)
+    with pytest.raises(V.NaNScore):
+        idx.search([float("inf"), 1.0], 1, 0)  # inf/inf
+    one = V.FlatIndex(2, [V.Vector(1, [1.0, 2.0])])
+    res = one.search([float("nan"), 0.0], 1, 3)  # 1 row: the comparator never runs
+    assert len(res) == 1 and res[0].score != res[0].score
+
+
+# ---------------------------------------------------------------------------------------------
+# trait surface: add / delete / get / errors (src/index/flat.rs:82-135)
+# ---------------------------------------------------------------------------------------------
+def test_trait_surface_and_errors(V, O):
+    idx = V.FlatIndex(3)
+    assert idx.is_empty() and len(idx) == 0 and idx.dimension() == 3 and idx.max_id() is None
+    assert idx.search([1, 2], 5, 0) == []  # empty index accepts any query length (:99)
+    idx.add(V.Vector(7, [1, 0, 0], "seven", {"k": 1}))
+    with pytest.raises(V.IndexOpError, match="Vector ID 7 already exists"):
+        idx.add(V.Vector(7, [0, 1, 0]))
+    with pytest.raises(V.IndexOpError, match="Vector dimension mismatch"):
+        idx.add(V.Vector(8, [0, 1]))
+    with pytest.raises(V.DimensionMismatch) as e:
+        idx.search([1, 2], 1, 0)
+    assert (e.value.expected, e.value.actual) == (3, 2)
+    idx.add(V.Vector(9, [0, 0, 0]))
+    idx.add(V.Vector(3, [-1, 0, 0]))
+    res = idx.search([1, 0, 0], 10, V.SimilarityMetric.Cosine)
+    assert [r.id for r in res] == [7, 9, 3] and [r.score for r in res] == [1.0, 0.0, -1.0]
+    assert res[0].text == "seven" and res[0].metadata == {"k": 1}
+    assert idx.search([1, 0, 0], 0, 0) == []
+    idx.delete(9)
+    idx.delete(12345)  # absent id: Ok
+    assert len(idx) == 2 and idx.max_id() == 7
+    assert [r.id for r in idx.search([1, 0, 0], 10, 0)] == [7, 3]
+    assert idx.get_vector(3).values == [-1.0, 0.0, 0.0] and idx.get_vector(9) is None
+    c = idx.clone()
+    idx.delete(7)
+    assert [r.id for r in c.search([1, 0, 0], 10, 0)] == [7, 3] and len(idx) == 1
+    ids, vals = c.export()
+    assert ids.tolist() == [7, 3] and vals.tolist() == [[1, 0, 0], [-1, 0, 0]]
+
+
+def test_add_delete_sequence_matches_oracle(V, O):
+    rng = np.random.default_rng(21)
+    dim = 40
+    gpu, ref = V.FlatIndex(dim), O.FlatOracle(dim)
+    live = []
+    next_id = 0
+    for step in range(400):
+        if live and rng.random() < 0.3:
+            victim = live.pop(int(rng.integers(len(live))))
+            gpu.delete(victim)
+            ref.delete(victim)
+        else:
+            v = unit_rows(rng, 1, dim)[0]
+            if rng.random() < 0.1 and live:
+                v = gpu.get_vector(live[0]).values  # duplicate content, new id
+            gpu.add(V.Vector(next_id, v))
+            ref.add(next_id, v)
+            live.append(next_id)
+            next_id += 1
+        if step % 40 == 39:
+            q = unit_rows(rng, 1, dim)[0]
+            for name, m in M.items():
+                assert_same(V, gpu.search_arrays(q, 7, m), ref.search(q, 7, m), (step, name))
+    assert len(gpu) == len(ref)
+
+
+def test_bulk_add_validation_stops_at_first_duplicate(V):
+    idx = V.FlatIndex(2)
+    idx.add_rows([1, 2, 3], np.eye(3, 2))
+    with pytest.raises(V.IndexOpError, match="Vector ID 2 already exists"):
+        idx.add_rows([4, 2, 5], np.ones((3, 2)))
+    assert len(idx) == 4 and idx.get_vector(4) is not None and idx.get_vector(5) is None
+    # FlatIndex::new keeps duplicate ids; delete removes all of them, get returns the first
+    dup = V.FlatIndex(2, [V.Vector(1, [1, 0]), V.Vector(1, [0, 1]), V.Vector(2, [1, 1])])
+    assert len(dup) == 3 and dup.get_vector(1).values == [1.0, 0.0]
+    dup.delete(1)
+    assert len(dup) == 1 and [r.id for r in dup.search([1, 1], 5, 0)] == [2]
+
+
+def test_search_batch_equals_single_searches(V, O):
+    rng = np.random.default_rng(8)
+    n, dim, nq, k = 3000, 128, 17, 10
+    rows = unit_rows(rng, n, dim)
+    ids = permuted_ids(n)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    Q = unit_rows(rng, nq, dim)
+    for name, m in M.items():
+        bi, bs, bn = gpu.search_batch(Q, k, m)
+        for i in range(nq):
+            ri, rs = ref.search(Q[i], k, m)
+            assert bn[i] == k and bi[i].tolist() == ri.tolist() and bs[i].tolist() == rs.tolist(), (name, i)
+
+
+def test_device_resident_ingest_matches_host_ingest(V, O):
+    import torch
+    rng = np.random.default_rng(2)
+    n, dim = 2000, 384
+    rows = unit_rows(rng, n, dim)
+    ids = permuted_ids(n)
+    a = V.FlatIndex(dim)
+    a.add_rows(ids, torch.from_numpy(rows).to("cuda:0"), validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    q = unit_rows(rng, 1, dim)[0]
+    for name, m in M.items():
+        assert_same(V, a.search_arrays(q, 10, m), ref.search(q, 10, m), name)
+    assert np.array_equal(a.export()[1], rows)
+
+
+# ---------------------------------------------------------------------------------------------
+# HNSW distance callbacks (src/index/hnsw.rs:113-174)
+# ---------------------------------------------------------------------------------------------
+def test_hnsw_distance_callbacks_bit_exact(V, O):
+    rng = np.random.default_rng(4)
+    for dim in (3, 96, 384, 500):
+        n = 300
+        rows = unit_rows(rng, n, dim) * rng.uniform(0.5, 30.0, size=(n, 1))
+        rows[3] = 0.0
+        gpu = V.FlatIndex(dim)
+        gpu.add_rows(np.arange(n, dtype=np.uint64), rows)
+        q = unit_rows(rng, 1, dim)[0] * 3.0
+        pos = rng.integers(0, n, size=150)
+        for name, m in M.items():
+            got = gpu.hnsw_distances(q, pos, m)
+            want = [O.hnsw_distance(m, q, rows[p]) for p in pos]
+            assert got.tolist() == want, (dim, name)
+    # reference fixture (src/index/hnsw.rs:605-634): d_u64 = 173, 1424, 1424, 911
+    gpu = V.FlatIndex(3, [V.Vector(100, [1, 0, 0]), V.Vector(200, [0, 1, 0]), V.Vector(300, [0, 0, 1]),
+                          V.Vector(400, [1, 1, 0])])
+    assert gpu.hnsw_distances([1.1, 0.1, 0.1], [0, 1, 2, 3], 1).tolist() == [173, 1424, 1424, 911]
+    # saturation: inf -> u64::MAX, NaN -> 0, zero norm -> 1000
+    big = V.FlatIndex(1, [V.Vector(1, [1e300]), V.Vector(2, [0.0])])
+    assert big.hnsw_distances([-1e300], [0], 1).tolist() == [2 ** 64 - 1]
+    assert big.hnsw_distances([1.0], [1], 0).tolist() == [1000]
+    assert big.hnsw_distances([float("nan")], [0], 3).tolist() == [0]

@@ -1,0 +1,340 @@
+"""vectorlite_amd -- MI355X-native distance-scan engine behind VectorLite's index interface.
+
+Python host-side mirror of the reference's operator interface for the ONE path this repo
+implements (reference = mmailhos/vectorlite v0.1.5, paths relative to /root/reference):
+
+    trait VectorIndex            src/lib.rs:224-245     -> FlatIndex.{add, delete, search, len, ...}
+    struct Vector / SearchResult src/lib.rs:164-203     -> Vector / SearchResult
+    enum SimilarityMetric        src/lib.rs:363-378     -> SimilarityMetric
+    VectorLiteError variants     src/errors.rs:18,42    -> DimensionMismatch / MetricMismatch
+
+Every numeric operation happens in libvectorlite_amd.so (HIP kernels, C ABI in
+include/vectorlite_amd.h).  This module only marshals buffers and re-attaches text/metadata to
+the k winners, which is what a Rust `impl VectorIndex for GpuFlatIndex` would do.
+No CPU fallback exists: without the built library, or without a GPU, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+__all__ = [
+    "SimilarityMetric", "Vector", "SearchResult", "FlatIndex", "VectorLiteError", "DimensionMismatch",
+    "MetricMismatch", "NaNScore", "DeviceError", "IndexOpError", "hnsw_score", "runtime_info",
+    "PATH_FAST", "PATH_EXACT_SELECT", "PATH_EXACT_SORT",
+]
+
+VL_OK, VL_ERR_DIM_MISMATCH, VL_ERR_DUP_ID, VL_ERR_NOT_FOUND, VL_ERR_METRIC_MISMATCH = 0, 1, 2, 3, 4
+VL_ERR_NAN_SCORE, VL_ERR_DEVICE, VL_ERR_OOM, VL_ERR_INVALID_ARG = 5, 6, 7, 8
+PATH_NONE, PATH_FAST, PATH_EXACT_SELECT, PATH_EXACT_SORT = 0, 1, 2, 3
+
+
+class SimilarityMetric(enum.IntEnum):
+    """enum SimilarityMetric (src/lib.rs:363-378); Cosine is the default."""
+    Cosine = 0
+    Euclidean = 1
+    Manhattan = 2
+    DotProduct = 3
+
+    @classmethod
+    def default(cls) -> "SimilarityMetric":
+        return cls.Cosine
+
+
+@dataclass
+class Vector:
+    """struct Vector (src/lib.rs:164-174)."""
+    id: int
+    values: Sequence[float]
+    text: str = ""
+    metadata: Optional[Any] = None
+
+
+@dataclass
+class SearchResult:
+    """struct SearchResult (src/lib.rs:194-203)."""
+    id: int
+    score: float
+    text: str = ""
+    metadata: Optional[Any] = None
+
+
+class VectorLiteError(Exception):
+    """enum VectorLiteError (src/errors.rs:11-67), the variants a search can return."""
+
+
+class DimensionMismatch(VectorLiteError):
+    def __init__(self, expected: int, actual: int):
+        super().__init__(f"Dimension mismatch: expected {expected}, got {actual}")
+        self.expected = expected
+        self.actual = actual
+
+
+class MetricMismatch(VectorLiteError):
+    def __init__(self, requested, index):
+        super().__init__(f"Metric mismatch: requested {requested!r}, index {index!r}")
+        self.requested = requested
+        self.index = index
+
+
+class NaNScore(VectorLiteError):
+    """Stands in for the reference's panic in `partial_cmp().unwrap()` (src/index/flat.rs:116)."""
+
+
+class DeviceError(VectorLiteError):
+    """HIP runtime failure or no GPU: there is no CPU fallback."""
+
+
+class IndexOpError(ValueError):
+    """add/delete return Err(String) in the reference (src/index/flat.rs:82-96); the message is the
+    reference's text ("Vector dimension mismatch", "Vector ID {id} already exists")."""
+
+
+def _last_error() -> str:
+    msg = _lib.load().vl_last_error()
+    return msg.decode() if msg else ""
+
+
+def _raise(rc: int):
+    if rc == VL_OK:
+        return
+    msg = _last_error()
+    if rc == VL_ERR_DIM_MISMATCH:
+        e, a = C.c_uint64(0), C.c_uint64(0)
+        _lib.load().vl_last_dim_mismatch(C.byref(e), C.byref(a))
+        raise DimensionMismatch(e.value, a.value)
+    if rc == VL_ERR_NAN_SCORE:
+        raise NaNScore(msg)
+    if rc in (VL_ERR_DEVICE, VL_ERR_OOM):
+        raise DeviceError(f"status {rc}: {msg}")
+    if rc == VL_ERR_METRIC_MISMATCH:
+        raise MetricMismatch(None, None)
+    raise VectorLiteError(f"status {rc}: {msg}")
+
+
+def runtime_info() -> Tuple[int, int]:
+    """(number of visible HIP devices, ABI version)."""
+    n, v = C.c_int(0), C.c_int(0)
+    _lib.load().vl_runtime_info(C.byref(n), C.byref(v))
+    return n.value, v.value
+
+
+def hnsw_score(d_u64: int, metric: int) -> float:
+    """convert_distance_to_similarity(d as f64 / 1000.0, metric) (src/index/hnsw.rs:51-75, :478-479)."""
+    return _lib.load().vl_hnsw_score(int(d_u64), int(metric))
+
+
+def last_path() -> int:
+    return _lib.load().vl_last_path()
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _pf64(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _pu64(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+class FlatIndex:
+    """GPU-resident counterpart of `FlatIndex` (src/index/flat.rs:60-135).
+
+    `FlatIndex(dim, data)` is `FlatIndex::new(dim, data)`: nothing is validated.
+    """
+
+    def __init__(self, dim: int, data: Sequence[Vector] = (), device: int = 0, _handle=None):
+        self._L = _lib.load()
+        self._meta: Dict[int, Tuple[str, Any]] = {}
+        self._h = C.c_void_p()
+        self.device = device
+        if _handle is not None:
+            self._h = _handle
+            return
+        data = list(data)
+        if data:
+            ids = np.ascontiguousarray(np.array([v.id for v in data], dtype=np.uint64))
+            vals = _f64([list(v.values) for v in data]).reshape(len(data), -1)
+            if vals.shape[1] != dim:
+                raise ValueError("FlatIndex(dim, data): rows must have `dim` values in this binding")
+            _raise(self._L.vl_flat_from_rows(dim, _pu64(ids), _pf64(vals), len(data), device, C.byref(self._h)))
+            for v in data:
+                self._meta.setdefault(int(v.id), (v.text, v.metadata))
+        else:
+            _raise(self._L.vl_flat_create(dim, device, C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self._L.vl_index_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # ---- trait VectorIndex ------------------------------------------------------------------
+    def add(self, vector: Vector) -> None:
+        vals = _f64(vector.values).ravel()
+        rc = self._L.vl_index_add(self._h, int(vector.id), _pf64(vals), vals.size)
+        if rc in (VL_ERR_DIM_MISMATCH, VL_ERR_DUP_ID):
+            raise IndexOpError(_last_error())
+        _raise(rc)
+        self._meta[int(vector.id)] = (vector.text, vector.metadata)
+
+    def delete(self, id: int) -> None:
+        _raise(self._L.vl_index_delete(self._h, int(id)))
+        self._meta.pop(int(id), None)
+
+    def search(self, query, k: int, similarity_metric: int = SimilarityMetric.Cosine) -> List[SearchResult]:
+        ids, scores = self.search_arrays(query, k, similarity_metric)
+        out = []
+        for i, s in zip(ids.tolist(), scores.tolist()):
+            text, md = self._meta.get(i, ("", None))
+            out.append(SearchResult(id=i, score=s, text=text, metadata=md))
+        return out
+
+    def len(self) -> int:
+        return int(self._L.vl_index_len(self._h))
+
+    __len__ = len
+
+    def is_empty(self) -> bool:
+        return bool(self._L.vl_index_is_empty(self._h))
+
+    def dimension(self) -> int:
+        return int(self._L.vl_index_dimension(self._h))
+
+    def get_vector(self, id: int) -> Optional[Vector]:
+        out = np.empty(max(self.dimension(), 1), dtype=np.float64)
+        rc = self._L.vl_index_get_vector(self._h, int(id), _pf64(out))
+        if rc == VL_ERR_NOT_FOUND:
+            return None
+        _raise(rc)
+        text, md = self._meta.get(int(id), ("", None))
+        return Vector(id=int(id), values=out[: self.dimension()].tolist(), text=text, metadata=md)
+
+    def max_id(self) -> Optional[int]:
+        out = C.c_uint64(0)
+        rc = self._L.vl_index_max_id(self._h, C.byref(out))
+        if rc == VL_ERR_NOT_FOUND:
+            return None
+        _raise(rc)
+        return out.value
+
+    # ---- array-level entry points -----------------------------------------------------------
+    def search_arrays(self, query, k: int, metric: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+        q = _f64(query).ravel()
+        m = max(min(int(k), self.len()), 1)
+        ids = np.empty(m, dtype=np.uint64)
+        scores = np.empty(m, dtype=np.float64)
+        n = C.c_uint64(0)
+        _raise(self._L.vl_index_search(self._h, _pf64(q), q.size, int(k), int(metric), _pu64(ids), _pf64(scores),
+                                       C.byref(n)))
+        return ids[: n.value].copy(), scores[: n.value].copy()
+
+    def search_positions(self, query, k: int, metric: int = 0):
+        """(positions, ids, scores): positions are storage positions, for row-shard merging."""
+        q = _f64(query).ravel()
+        m = max(min(int(k), self.len()), 1)
+        pos = np.empty(m, dtype=np.uint64)
+        ids = np.empty(m, dtype=np.uint64)
+        scores = np.empty(m, dtype=np.float64)
+        n = C.c_uint64(0)
+        _raise(self._L.vl_index_search_positions(self._h, _pf64(q), q.size, int(k), int(metric), _pu64(pos),
+                                                 _pu64(ids), _pf64(scores), C.byref(n)))
+        return pos[: n.value].copy(), ids[: n.value].copy(), scores[: n.value].copy()
+
+    def search_batch(self, queries, k: int, metric: int = 0):
+        """New capability (no reference counterpart): nq independent searches.
+        Returns (ids [nq, k], scores [nq, k], n [nq]); row i is exactly search(queries[i])."""
+        Q = _f64(queries)
+        if Q.ndim != 2:
+            raise ValueError("queries must be [nq, dim]")
+        nq, qlen = Q.shape
+        kk = max(int(k), 1)
+        ids = np.zeros((nq, kk), dtype=np.uint64)
+        scores = np.zeros((nq, kk), dtype=np.float64)
+        n = np.zeros(max(nq, 1), dtype=np.uint64)
+        _raise(self._L.vl_index_search_batch(self._h, _pf64(Q), nq, qlen, int(k), int(metric), _pu64(ids),
+                                             _pf64(scores), _pu64(n)))
+        return ids[:, : int(k)], scores[:, : int(k)], n[:nq]
+
+    def add_rows(self, ids, values, validate: bool = True) -> None:
+        """n x add() in one device pass.  `values`: [n, dim] f64 numpy array, or a torch CUDA/HIP
+        tensor (f64, contiguous, on this index's device) which is ingested device-to-device."""
+        ids = np.ascontiguousarray(np.asarray(ids, dtype=np.uint64))
+        n = ids.size
+        on_device = False
+        try:
+            import torch
+            is_tensor = isinstance(values, torch.Tensor)
+        except Exception:  # pragma: no cover
+            is_tensor = False
+        if is_tensor:
+            import torch
+            if values.dtype != torch.float64 or not values.is_contiguous():
+                raise ValueError("device rows must be a contiguous float64 tensor")
+            if values.numel() != n * self.dimension():
+                raise ValueError("values must be [n, dim]")
+            if values.is_cuda:
+                torch.cuda.current_stream(values.device).synchronize()  # producer kernels are done
+                on_device = True
+                ptr = C.c_void_p(values.data_ptr())
+            else:
+                values = values.numpy()
+        if not on_device:
+            vals = _f64(values)
+            if vals.size != n * self.dimension():
+                raise ValueError("values must be [n, dim]")
+            ptr = C.c_void_p(vals.ctypes.data)
+        rc = self._L.vl_index_add_bulk(self._h, _pu64(ids), ptr, n, 1 if validate else 0, 1 if on_device else 0)
+        if rc == VL_ERR_DUP_ID:
+            raise IndexOpError(_last_error())
+        _raise(rc)
+
+    def reserve(self, n_rows: int) -> None:
+        _raise(self._L.vl_index_reserve(self._h, int(n_rows)))
+
+    def clone(self) -> "FlatIndex":
+        h = C.c_void_p()
+        _raise(self._L.vl_index_clone(self._h, C.byref(h)))
+        c = FlatIndex(self.dimension(), device=self.device, _handle=h)
+        c._meta = dict(self._meta)
+        return c
+
+    def export(self) -> Tuple[np.ndarray, np.ndarray]:
+        n, d = self.len(), self.dimension()
+        ids = np.empty(max(n, 1), dtype=np.uint64)
+        vals = np.empty((max(n, 1), max(d, 1)), dtype=np.float64)
+        _raise(self._L.vl_index_export(self._h, _pu64(ids), _pf64(vals)))
+        return ids[:n].copy(), vals[:n, :d].copy()
+
+    def hnsw_distances(self, query, positions, metric: int) -> np.ndarray:
+        """Metric::distance(query, row) -> u64 for the rows at `positions` (src/index/hnsw.rs:113-174)."""
+        q = _f64(query).ravel()
+        pos = np.ascontiguousarray(np.asarray(positions, dtype=np.uint64))
+        out = np.empty(max(pos.size, 1), dtype=np.uint64)
+        _raise(self._L.vl_index_hnsw_distances(self._h, _pf64(q), q.size, int(metric), _pu64(pos), pos.size,
+                                               _pu64(out)))
+        return out[: pos.size].copy()
+
+    # ---- diagnostics ------------------------------------------------------------------------
+    def force_path(self, path: int) -> None:
+        _raise(self._L.vl_index_force_path(self._h, int(path)))
+
+    def profile_enable(self, on: bool) -> None:
+        _raise(self._L.vl_index_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self) -> Tuple[int, float, int]:
+        n, ms, b = C.c_uint64(0), C.c_double(0.0), C.c_uint64(0)
+        _raise(self._L.vl_index_profile_read(self._h, C.byref(n), C.byref(ms), C.byref(b)))
+        return n.value, ms.value, b.value

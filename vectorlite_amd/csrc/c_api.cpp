@@ -1,0 +1,237 @@
+// c_api.cpp -- extern "C" boundary (include/vectorlite_amd.h) over vl::GpuFlatIndex.
+// No C++ exception crosses it: every entry point catches and maps to a vl_status.
+#include "../../include/vectorlite_amd.h"
+
+#include <new>
+#include <stdexcept>
+
+#include "flat_index.hpp"
+
+struct vl_index {
+    vl::GpuFlatIndex* flat;
+};
+
+namespace {
+constexpr int VL_ABI_VERSION = 1;
+
+template <typename F>
+int guarded(F&& f)
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        vl::set_last_error("host allocation failed");
+        return VL_ERR_OOM;
+    } catch (const std::exception& e) {
+        vl::set_last_error(std::string("internal error: ") + e.what());
+        return VL_ERR_DEVICE;
+    } catch (...) {
+        vl::set_last_error("internal error");
+        return VL_ERR_DEVICE;
+    }
+}
+
+int wrap(vl::GpuFlatIndex* idx, vl_index** out)
+{
+    vl_index* h = new (std::nothrow) vl_index{idx};
+    if (!h) {
+        delete idx;
+        return VL_ERR_OOM;
+    }
+    *out = h;
+    return VL_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int vl_flat_create(uint64_t dim, int device, vl_index** out)
+{
+    return guarded([&]() -> int {
+        if (!out) return VL_ERR_INVALID_ARG;
+        *out = nullptr;
+        vl::GpuFlatIndex* idx = nullptr;
+        int rc = vl::GpuFlatIndex::create(dim, device, &idx);
+        if (rc != VL_OK) return rc;
+        return wrap(idx, out);
+    });
+}
+
+int vl_flat_from_rows(uint64_t dim, const uint64_t* ids, const double* values, uint64_t n, int device,
+                      vl_index** out)
+{
+    return guarded([&]() -> int {
+        if (!out) return VL_ERR_INVALID_ARG;
+        *out = nullptr;
+        vl::GpuFlatIndex* idx = nullptr;
+        int rc = vl::GpuFlatIndex::create(dim, device, &idx);
+        if (rc != VL_OK) return rc;
+        rc = idx->add_bulk(ids, values, n, /*validate=*/false, /*values_on_device=*/false);
+        if (rc != VL_OK) {
+            delete idx;
+            return rc;
+        }
+        return wrap(idx, out);
+    });
+}
+
+int vl_index_clone(const vl_index* h, vl_index** out)
+{
+    return guarded([&]() -> int {
+        if (!h || !out) return VL_ERR_INVALID_ARG;
+        *out = nullptr;
+        vl::GpuFlatIndex* c = nullptr;
+        int rc = h->flat->clone(&c);
+        if (rc != VL_OK) return rc;
+        return wrap(c, out);
+    });
+}
+
+void vl_index_destroy(vl_index* h)
+{
+    if (!h) return;
+    try {
+        delete h->flat;
+    } catch (...) {
+    }
+    delete h;
+}
+
+int vl_index_reserve(vl_index* h, uint64_t n_rows)
+{
+    return guarded([&]() -> int { return h ? h->flat->reserve(n_rows) : (int)VL_ERR_INVALID_ARG; });
+}
+
+int vl_index_add(vl_index* h, uint64_t id, const double* values, uint64_t len)
+{
+    return guarded([&]() -> int { return h ? h->flat->add(id, values, len) : (int)VL_ERR_INVALID_ARG; });
+}
+
+int vl_index_add_bulk(vl_index* h, const uint64_t* ids, const double* values, uint64_t n, int validate,
+                      int values_on_device)
+{
+    return guarded([&]() -> int {
+        return h ? h->flat->add_bulk(ids, values, n, validate != 0, values_on_device != 0)
+                 : (int)VL_ERR_INVALID_ARG;
+    });
+}
+
+int vl_index_delete(vl_index* h, uint64_t id)
+{
+    return guarded([&]() -> int { return h ? h->flat->remove(id) : (int)VL_ERR_INVALID_ARG; });
+}
+
+int vl_index_search(const vl_index* h, const double* query, uint64_t q_len, uint64_t k, int metric,
+                    uint64_t* out_ids, double* out_scores, uint64_t* out_n)
+{
+    return guarded([&]() -> int {
+        if (!h || !out_n) return VL_ERR_INVALID_ARG;
+        if (!out_ids && k != 0 && h->flat->len() != 0) return VL_ERR_INVALID_ARG;
+        return h->flat->search(query, q_len, k, metric, nullptr, out_ids, out_scores, out_n);
+    });
+}
+
+int vl_index_search_positions(const vl_index* h, const double* query, uint64_t q_len, uint64_t k, int metric,
+                              uint64_t* out_pos, uint64_t* out_ids, double* out_scores, uint64_t* out_n)
+{
+    return guarded([&]() -> int {
+        if (!h || !out_n) return VL_ERR_INVALID_ARG;
+        return h->flat->search(query, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
+    });
+}
+
+int vl_index_search_batch(const vl_index* h, const double* queries, uint64_t nq, uint64_t q_len, uint64_t k,
+                          int metric, uint64_t* out_ids, double* out_scores, uint64_t* out_n)
+{
+    return guarded([&]() -> int {
+        if (!h || (!out_n && nq)) return VL_ERR_INVALID_ARG;
+        for (uint64_t i = 0; i < nq; ++i) {
+            int rc = h->flat->search(queries + i * q_len, q_len, k, metric, nullptr, out_ids + i * k,
+                                     out_scores + i * k, out_n + i);
+            if (rc != VL_OK) return rc;
+        }
+        return VL_OK;
+    });
+}
+
+uint64_t vl_index_len(const vl_index* h) { return h ? h->flat->len() : 0; }
+int vl_index_is_empty(const vl_index* h) { return h ? (h->flat->len() == 0) : 1; }
+uint64_t vl_index_dimension(const vl_index* h) { return h ? h->flat->dimension() : 0; }
+
+int vl_index_get_vector(const vl_index* h, uint64_t id, double* out_values)
+{
+    return guarded([&]() -> int { return h ? h->flat->get_vector(id, out_values) : (int)VL_ERR_INVALID_ARG; });
+}
+
+int vl_index_max_id(const vl_index* h, uint64_t* out_id)
+{
+    return guarded([&]() -> int { return h ? h->flat->max_id(out_id) : (int)VL_ERR_INVALID_ARG; });
+}
+
+int vl_index_export(const vl_index* h, uint64_t* out_ids, double* out_values)
+{
+    return guarded([&]() -> int { return h ? h->flat->export_rows(out_ids, out_values) : (int)VL_ERR_INVALID_ARG; });
+}
+
+int vl_index_hnsw_distances(const vl_index* h, const double* query, uint64_t q_len, int metric,
+                            const uint64_t* positions, uint64_t m, uint64_t* out_dist)
+{
+    return guarded([&]() -> int {
+        return h ? h->flat->hnsw_distances(query, q_len, metric, positions, m, out_dist) : (int)VL_ERR_INVALID_ARG;
+    });
+}
+
+// convert_distance_to_similarity(d as f64 / 1000.0, metric): src/index/hnsw.rs:51-75, :478-479.
+// Four scalar operations on the k winners' u64 distances; no vector data is touched here.
+double vl_hnsw_score(uint64_t d_u64, int metric)
+{
+    const double distance = (double)d_u64 / 1000.0;
+    switch (metric) {
+    case VL_EUCLIDEAN:
+    case VL_MANHATTAN: return 1.0 / (1.0 + distance);
+    case VL_COSINE: return 1.0 - distance / 1000.0;
+    default: {
+        double v = (1000.0 - distance) / 1000.0;
+        if (v < 0.0) v = 0.0;
+        if (v > 1.0) v = 1.0;
+        return v;
+    }
+    }
+}
+
+const char* vl_last_error(void) { return vl::last_error(); }
+void vl_last_dim_mismatch(uint64_t* expected, uint64_t* actual) { vl::get_dim_mismatch(expected, actual); }
+int vl_last_path(void) { return vl::last_path(); }
+
+int vl_index_force_path(vl_index* h, int path)
+{
+    if (!h || (path != 0 && path != VL_PATH_EXACT_SELECT && path != VL_PATH_EXACT_SORT)) return VL_ERR_INVALID_ARG;
+    h->flat->force_path(path);
+    return VL_OK;
+}
+
+int vl_index_profile_enable(vl_index* h, int enable)
+{
+    if (!h) return VL_ERR_INVALID_ARG;
+    h->flat->profile_enable(enable != 0);
+    return VL_OK;
+}
+
+int vl_index_profile_read(vl_index* h, uint64_t* n_scan_launches, double* scan_ms_total, uint64_t* scan_bytes_total)
+{
+    if (!h) return VL_ERR_INVALID_ARG;
+    h->flat->profile_read(n_scan_launches, scan_ms_total, scan_bytes_total);
+    return VL_OK;
+}
+
+int vl_runtime_info(int* n_devices, int* abi_version)
+{
+    if (abi_version) *abi_version = VL_ABI_VERSION;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    if (n_devices) *n_devices = n;
+    return VL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,707 @@
+// flat_index.cpp -- host logic of the GPU flat index (see flat_index.hpp).
+//
+// Mirrors `impl VectorIndex for FlatIndex` (reference src/index/flat.rs:82-135): same argument
+// meaning, same error behaviour, same result order.  All arithmetic on vectors runs in the HIP
+// kernels (kernels.hip); the host only stages queries, keeps the position -> id table and maps
+// positions back to ids for the k winners (the reference re-attaches text/metadata the same way,
+// src/index/flat.rs:106-114).  There is no CPU compute fallback.
+#include "flat_index.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace vl {
+
+// ---------------------------------------------------------------------------------------------
+// thread-local diagnostics
+// ---------------------------------------------------------------------------------------------
+namespace {
+thread_local std::string t_last_error;
+thread_local uint64_t t_dim_expected = 0, t_dim_actual = 0;
+thread_local int t_last_path = PATH_NONE;
+}  // namespace
+
+void set_last_error(const std::string& msg) { t_last_error = msg; }
+const char* last_error() { return t_last_error.c_str(); }
+void set_dim_mismatch(uint64_t expected, uint64_t actual)
+{
+    t_dim_expected = expected;
+    t_dim_actual = actual;
+}
+void get_dim_mismatch(uint64_t* expected, uint64_t* actual)
+{
+    if (expected) *expected = t_dim_expected;
+    if (actual) *actual = t_dim_actual;
+}
+void set_last_path(int p) { t_last_path = p; }
+int last_path() { return t_last_path; }
+
+#define VL_HIP(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_));                   \
+            return (e_ == hipErrorOutOfMemory) ? (int)ERR_OOM : (int)ERR_DEVICE;                 \
+        }                                                                                        \
+    } while (0)
+
+#define VL_TRY(expr)              \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != OK) return rc_; \
+    } while (0)
+
+namespace {
+constexpr double DOMAIN_MAX_ABS = 1099511627776.0;          // 2^40
+constexpr double DOMAIN_MIN_NORM = 9.094947017729282e-13;   // 2^-40
+constexpr size_t BOUNCE_BYTES = 64ull << 20;
+
+template <typename T>
+int dev_alloc(T** p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) return OK;
+    VL_HIP(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    return OK;
+}
+template <typename T>
+int pinned_alloc(T** p, size_t count)
+{
+    *p = nullptr;
+    VL_HIP(hipHostMalloc(reinterpret_cast<void**>(p), count * sizeof(T), hipHostMallocDefault));
+    return OK;
+}
+}  // namespace
+
+Workspace::~Workspace()
+{
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    void* dev[] = {d_q32, d_q64, d_partials, d_partials64, d_result, d_nan, d_scores, d_okeys,
+                   d_opos, d_out_pos, d_out_scores, d_positions, d_dists};
+    for (void* p : dev)
+        if (p) (void)hipFree(p);
+    void* host[] = {h_q32, h_q64, h_result, h_nan};
+    for (void* p : host)
+        if (p) (void)hipHostFree(p);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// lifecycle
+// ---------------------------------------------------------------------------------------------
+GpuFlatIndex::GpuFlatIndex(uint64_t dim, int device)
+    : dim_(dim), ld_((uint32_t)((dim + 3) & ~3ull)), device_(device)
+{
+}
+
+int GpuFlatIndex::create(uint64_t dim, int device, GpuFlatIndex** out)
+{
+    if (!out) return ERR_INVALID_ARG;
+    *out = nullptr;
+    if (dim == 0 || dim > 0x0FFFFFFFull) {
+        set_last_error("dimension must be in [1, 2^28)");
+        return ERR_INVALID_ARG;
+    }
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        set_last_error("no HIP device visible: vectorlite_amd has no CPU fallback");
+        return ERR_DEVICE;
+    }
+    if (device < 0 || device >= n_dev) {
+        set_last_error("device ordinal out of range");
+        return ERR_DEVICE;
+    }
+    VL_HIP(hipSetDevice(device));
+    std::unique_ptr<GpuFlatIndex> idx(new GpuFlatIndex(dim, device));
+    VL_HIP(hipStreamCreateWithFlags(&idx->mut_stream_, hipStreamNonBlocking));
+    VL_TRY(dev_alloc(&idx->d_stats_, 1));
+    VL_HIP(hipMemsetAsync(idx->d_stats_, 0, sizeof(IngestStats), idx->mut_stream_));
+    VL_HIP(hipStreamSynchronize(idx->mut_stream_));
+    *out = idx.release();
+    return OK;
+}
+
+GpuFlatIndex::~GpuFlatIndex()
+{
+    (void)hipSetDevice(device_);
+    ws_all_.clear();
+    if (mut_stream_) (void)hipStreamSynchronize(mut_stream_);
+    void* dev[] = {d_master_, d_slab_, d_inv_norm_, d_flags_, d_stats_, d_bounce_};
+    for (void* p : dev)
+        if (p) (void)hipFree(p);
+    if (mut_stream_) (void)hipStreamDestroy(mut_stream_);
+}
+
+uint64_t GpuFlatIndex::len() const
+{
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    return ids_.size();
+}
+
+int GpuFlatIndex::reserve(uint64_t n_rows)
+{
+    std::unique_lock<std::shared_mutex> lk(mu_);
+    VL_HIP(hipSetDevice(device_));
+    return ensure_capacity(n_rows);
+}
+
+int GpuFlatIndex::ensure_capacity(uint64_t rows)
+{
+    if (rows <= cap_) return OK;
+    if (rows >= 0xFFFFFFF0ull) {
+        set_last_error("row count exceeds the u32 position space");
+        return ERR_INVALID_ARG;
+    }
+    uint64_t grown = cap_ < (1ull << 20) ? cap_ * 2 : cap_ + cap_ / 2;
+    uint64_t new_cap = std::max<uint64_t>({rows, grown, 1024});
+    double* m = nullptr;
+    float* s = nullptr;
+    float* inv = nullptr;
+    uint8_t* fl = nullptr;
+    const uint64_t dim_alloc = dim_ ? dim_ : 1;
+    int rc = dev_alloc(&m, new_cap * dim_alloc);
+    if (rc == OK) rc = dev_alloc(&s, new_cap * (ld_ ? ld_ : 4));
+    if (rc == OK) rc = dev_alloc(&inv, new_cap);
+    if (rc == OK) rc = dev_alloc(&fl, new_cap);
+    if (rc != OK) {
+        if (m) (void)hipFree(m);
+        if (s) (void)hipFree(s);
+        if (inv) (void)hipFree(inv);
+        if (fl) (void)hipFree(fl);
+        return rc;
+    }
+    const uint64_t n = ids_.size();
+    if (n) {
+        VL_HIP(hipMemcpyAsync(m, d_master_, n * dim_ * sizeof(double), hipMemcpyDeviceToDevice, mut_stream_));
+        VL_HIP(hipMemcpyAsync(s, d_slab_, n * ld_ * sizeof(float), hipMemcpyDeviceToDevice, mut_stream_));
+        VL_HIP(hipMemcpyAsync(inv, d_inv_norm_, n * sizeof(float), hipMemcpyDeviceToDevice, mut_stream_));
+        VL_HIP(hipMemcpyAsync(fl, d_flags_, n, hipMemcpyDeviceToDevice, mut_stream_));
+    }
+    VL_HIP(hipStreamSynchronize(mut_stream_));
+    if (d_master_) (void)hipFree(d_master_);
+    if (d_slab_) (void)hipFree(d_slab_);
+    if (d_inv_norm_) (void)hipFree(d_inv_norm_);
+    if (d_flags_) (void)hipFree(d_flags_);
+    d_master_ = m;
+    d_slab_ = s;
+    d_inv_norm_ = inv;
+    d_flags_ = fl;
+    cap_ = new_cap;
+    return OK;
+}
+
+// Rows [first, first+n) of d_master_ are in place: derive slab / inv_norm / flags / stats.
+int GpuFlatIndex::ingest_range(uint64_t first, uint64_t n)
+{
+    if (n == 0) return OK;
+    VL_HIP(launch_ingest(mut_stream_, d_master_ + first * dim_, d_slab_ + first * ld_, d_inv_norm_ + first,
+                         d_flags_ + first, d_stats_, n, (uint32_t)dim_, ld_));
+    std::vector<uint8_t> fl(n);
+    IngestStats st;
+    VL_HIP(hipMemcpyAsync(fl.data(), d_flags_ + first, n, hipMemcpyDeviceToHost, mut_stream_));
+    VL_HIP(hipMemcpyAsync(&st, d_stats_, sizeof(st), hipMemcpyDeviceToHost, mut_stream_));
+    VL_HIP(hipStreamSynchronize(mut_stream_));
+    row_flags_.resize(first + n);
+    for (uint64_t i = 0; i < n; ++i) {
+        row_flags_[first + i] = fl[i];
+        if (fl[i] & ROW_OUT_OF_DOMAIN) ++n_out_of_domain_;
+    }
+    double mn;
+    static_assert(sizeof(mn) == sizeof(st.max_norm_bits), "f64 bits");
+    std::memcpy(&mn, &st.max_norm_bits, sizeof(mn));
+    if (mn > max_row_norm_) max_row_norm_ = mn;
+    return OK;
+}
+
+void GpuFlatIndex::rebuild_id_counts() const
+{
+    id_counts_.clear();
+    id_counts_.reserve(ids_.size() * 2);
+    for (uint64_t id : ids_) ++id_counts_[id];
+    id_counts_valid_ = true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// add / delete
+// ---------------------------------------------------------------------------------------------
+int GpuFlatIndex::add(uint64_t id, const double* values, uint64_t len)
+{
+    if (len != dim_) {  // src/index/flat.rs:83-85
+        set_dim_mismatch(dim_, len);
+        set_last_error("Vector dimension mismatch");
+        return ERR_DIM_MISMATCH;
+    }
+    if (!values && dim_) return ERR_INVALID_ARG;
+    return add_bulk(&id, values, 1, /*validate=*/true, /*values_on_device=*/false);
+}
+
+int GpuFlatIndex::add_bulk(const uint64_t* ids, const double* values, uint64_t n, bool validate,
+                           bool values_on_device)
+{
+    if (n == 0) return OK;
+    if (!ids || (!values && dim_)) return ERR_INVALID_ARG;
+    std::unique_lock<std::shared_mutex> lk(mu_);
+    VL_HIP(hipSetDevice(device_));
+
+    uint64_t n_take = n;
+    int rc_after = OK;
+    if (validate) {  // n sequential add() calls: stop at the first duplicate id (src/index/flat.rs:86-88)
+        if (!id_counts_valid_) rebuild_id_counts();
+        for (uint64_t i = 0; i < n; ++i) {
+            auto it = id_counts_.find(ids[i]);
+            if (it != id_counts_.end() && it->second > 0) {
+                n_take = i;
+                rc_after = ERR_DUP_ID;
+                set_last_error("Vector ID " + std::to_string(ids[i]) + " already exists");
+                break;
+            }
+            ++id_counts_[ids[i]];
+        }
+    } else {
+        id_counts_valid_ = false;  // FlatIndex::new validates nothing; counts are rebuilt on demand
+    }
+    if (n_take == 0) return rc_after;
+
+    const uint64_t first = ids_.size();
+    int rc = ensure_capacity(first + n_take);
+    if (rc == OK && dim_) {
+        hipError_t e = hipMemcpyAsync(d_master_ + first * dim_, values, n_take * dim_ * sizeof(double),
+                                      values_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                      mut_stream_);
+        if (e != hipSuccess) {
+            set_last_error(std::string("hipMemcpyAsync(rows): ") + hipGetErrorString(e));
+            rc = ERR_DEVICE;
+        }
+    }
+    if (rc == OK) rc = ingest_range(first, n_take);
+    if (rc != OK) {
+        if (validate)  // roll the id bookkeeping back
+            for (uint64_t i = 0; i < n_take; ++i) --id_counts_[ids[i]];
+        return rc;
+    }
+    ids_.insert(ids_.end(), ids, ids + n_take);
+    return rc_after;
+}
+
+// Order-preserving removal of one row (Vec::retain, src/index/flat.rs:94): rows behind it move up
+// by one.  Overlapping device ranges are moved through a bounce buffer in ascending chunks.
+int GpuFlatIndex::remove_position(uint64_t pos)
+{
+    const uint64_t n = ids_.size();
+    const uint64_t tail = n - pos - 1;
+    if (tail) {
+        if (!d_bounce_) {
+            VL_HIP(hipMalloc(&d_bounce_, BOUNCE_BYTES));
+            bounce_bytes_ = BOUNCE_BYTES;
+        }
+        struct Buf {
+            char* base;
+            size_t row_bytes;
+        } bufs[] = {{reinterpret_cast<char*>(d_master_), dim_ * sizeof(double)},
+                    {reinterpret_cast<char*>(d_slab_), ld_ * sizeof(float)},
+                    {reinterpret_cast<char*>(d_inv_norm_), sizeof(float)},
+                    {reinterpret_cast<char*>(d_flags_), 1}};
+        for (const Buf& b : bufs) {
+            if (b.row_bytes == 0) continue;
+            char* dst = b.base + pos * b.row_bytes;
+            const char* src = dst + b.row_bytes;
+            const size_t total = tail * b.row_bytes;
+            for (size_t off = 0; off < total; off += bounce_bytes_) {
+                const size_t c = std::min(bounce_bytes_, total - off);
+                VL_HIP(hipMemcpyAsync(d_bounce_, src + off, c, hipMemcpyDeviceToDevice, mut_stream_));
+                VL_HIP(hipMemcpyAsync(dst + off, d_bounce_, c, hipMemcpyDeviceToDevice, mut_stream_));
+            }
+        }
+        VL_HIP(hipStreamSynchronize(mut_stream_));
+    }
+    if (row_flags_[pos] & ROW_OUT_OF_DOMAIN) --n_out_of_domain_;
+    ids_.erase(ids_.begin() + pos);
+    row_flags_.erase(row_flags_.begin() + pos);
+    return OK;
+}
+
+int GpuFlatIndex::remove(uint64_t id)
+{
+    std::unique_lock<std::shared_mutex> lk(mu_);
+    VL_HIP(hipSetDevice(device_));
+    // retain(|e| e.id != id): every matching row goes, highest position first
+    for (uint64_t p = ids_.size(); p-- > 0;) {
+        if (ids_[p] == id) {
+            VL_TRY(remove_position(p));
+            if (id_counts_valid_) {
+                auto it = id_counts_.find(id);
+                if (it != id_counts_.end() && it->second > 0) --it->second;
+            }
+        }
+    }
+    return OK;  // absent id is Ok(()) (src/index/flat.rs:93-96)
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspaces
+// ---------------------------------------------------------------------------------------------
+int GpuFlatIndex::prepare_ws(Workspace* ws) const
+{
+    ws->device = device_;
+    VL_HIP(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
+    const size_t qn = std::max<size_t>(ld_, 4);
+    ws->q_cap = qn;
+    VL_TRY(dev_alloc(&ws->d_q32, qn));
+    VL_TRY(dev_alloc(&ws->d_q64, qn));
+    VL_TRY(pinned_alloc(&ws->h_q32, qn));
+    VL_TRY(pinned_alloc(&ws->h_q64, qn));
+    VL_TRY(dev_alloc(&ws->d_partials, (size_t)SCAN_MAX_GRID * KP));
+    VL_TRY(dev_alloc(&ws->d_partials64, (size_t)1024 * KP));
+    VL_TRY(dev_alloc(&ws->d_result, 1));
+    VL_TRY(pinned_alloc(&ws->h_result, 1));
+    VL_TRY(dev_alloc(&ws->d_nan, 1));
+    VL_TRY(pinned_alloc(&ws->h_nan, 1));
+    VL_HIP(hipEventCreate(&ws->ev0));
+    VL_HIP(hipEventCreate(&ws->ev1));
+    return OK;
+}
+
+Workspace* GpuFlatIndex::acquire_ws() const
+{
+    {
+        std::lock_guard<std::mutex> g(ws_mu_);
+        if (!ws_free_.empty()) {
+            Workspace* w = ws_free_.back();
+            ws_free_.pop_back();
+            return w;
+        }
+    }
+    std::unique_ptr<Workspace> w(new Workspace());
+    if (prepare_ws(w.get()) != OK) return nullptr;
+    Workspace* raw = w.get();
+    std::lock_guard<std::mutex> g(ws_mu_);
+    ws_all_.push_back(std::move(w));
+    return raw;
+}
+
+void GpuFlatIndex::release_ws(Workspace* ws) const
+{
+    std::lock_guard<std::mutex> g(ws_mu_);
+    ws_free_.push_back(ws);
+}
+
+void GpuFlatIndex::profile_enable(bool on) { profile_.store(on); }
+
+void GpuFlatIndex::profile_read(uint64_t* n, double* ms, uint64_t* bytes)
+{
+    std::lock_guard<std::mutex> g(prof_mu_);
+    if (n) *n = prof_n_;
+    if (ms) *ms = prof_ms_;
+    if (bytes) *bytes = prof_bytes_;
+    prof_n_ = 0;
+    prof_ms_ = 0.0;
+    prof_bytes_ = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// search (src/index/flat.rs:98-119)
+// ---------------------------------------------------------------------------------------------
+int GpuFlatIndex::search(const double* query, uint64_t q_len, uint64_t k, int metric, uint64_t* out_pos,
+                         uint64_t* out_ids, double* out_scores, uint64_t* out_n) const
+{
+    if (!out_n) return ERR_INVALID_ARG;
+    *out_n = 0;
+    if (metric < 0 || metric > 3) {
+        set_last_error("unknown metric");
+        return ERR_INVALID_ARG;
+    }
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    const uint64_t n = ids_.size();
+    if (n != 0 && q_len != dim_) {  // :99-104 (skipped while the index is empty)
+        set_dim_mismatch(dim_, q_len);
+        set_last_error("Dimension mismatch: expected " + std::to_string(dim_) + ", got " + std::to_string(q_len));
+        return ERR_DIM_MISMATCH;
+    }
+    if (n == 0 || k == 0) return OK;  // truncate(0) / nothing stored
+    if ((!query && dim_) || !out_scores) return ERR_INVALID_ARG;
+    const uint64_t k_eff = std::min<uint64_t>(k, n);
+
+    VL_HIP(hipSetDevice(device_));
+    Workspace* ws = acquire_ws();
+    if (!ws) return ERR_DEVICE;
+    const int rc = search_locked(ws, query, k_eff, metric, out_pos, out_ids, out_scores, out_n);
+    if (rc != OK) (void)hipStreamSynchronize(ws->stream);
+    release_ws(ws);
+    return rc;
+}
+
+int GpuFlatIndex::search_locked(Workspace* ws, const double* query, uint64_t k_eff, int metric,
+                                uint64_t* out_pos, uint64_t* out_ids, double* out_scores, uint64_t* out_n) const
+{
+    const uint64_t n = ids_.size();
+    hipStream_t st = ws->stream;
+
+    // stage the query: f64 (exact kernels) and f32 zero-padded to ld (scan)
+    double qq = 0.0, qmax = 0.0;
+    bool q_finite = true;
+    for (uint64_t i = 0; i < dim_; ++i) {
+        const double v = query[i];
+        ws->h_q64[i] = v;
+        ws->h_q32[i] = (float)v;
+        qq += v * v;
+        const double av = std::fabs(v);
+        if (!(av <= 1.797693134862315708e308)) q_finite = false;
+        if (av > qmax) qmax = av;
+    }
+    for (uint64_t i = dim_; i < ld_; ++i) ws->h_q32[i] = 0.0f;
+    const double q_norm = std::sqrt(qq);
+    const bool q_in_domain = q_finite && qmax <= DOMAIN_MAX_ABS && (q_norm == 0.0 || q_norm >= DOMAIN_MIN_NORM);
+    if (dim_) {
+        VL_HIP(hipMemcpyAsync(ws->d_q64, ws->h_q64, dim_ * sizeof(double), hipMemcpyHostToDevice, st));
+        VL_HIP(hipMemcpyAsync(ws->d_q32, ws->h_q32, ld_ * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+
+    const int forced = force_path_.load();
+    const bool fast_ok = forced == 0 && dim_ > 0 && k_eff <= (uint64_t)KFAST_MAX && n_out_of_domain_ == 0 &&
+                         q_in_domain;
+    if (fast_ok) {
+        const bool prof = profile_.load();
+        ScanPlan plan;
+        if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
+        VL_HIP(launch_scan(st, metric, d_slab_, d_inv_norm_, ws->d_q32, n, ld_, ws->d_partials, &plan));
+        if (prof) VL_HIP(hipEventRecord(ws->ev1, st));
+        VL_HIP(launch_merge_finalize(st, metric, ws->d_partials, plan.grid, d_master_, ws->d_q64, (uint32_t)dim_,
+                                     n, (uint32_t)k_eff, max_row_norm_, q_norm, ws->d_result));
+        VL_HIP(hipMemcpyAsync(ws->h_result, ws->d_result, sizeof(SearchResultBlock), hipMemcpyDeviceToHost, st));
+        VL_HIP(hipStreamSynchronize(st));
+        if (prof) {
+            float ms = 0.f;
+            VL_HIP(hipEventElapsedTime(&ms, ws->ev0, ws->ev1));
+            std::lock_guard<std::mutex> g(prof_mu_);
+            prof_n_ += 1;
+            prof_ms_ += ms;
+            prof_bytes_ += n * (uint64_t)ld_ * sizeof(float);
+        }
+        const SearchResultBlock& r = *ws->h_result;
+        if (!(r.flags & RESULT_NEEDS_EXACT) && r.n_out == k_eff) {
+            for (uint64_t i = 0; i < k_eff; ++i) {
+                const uint32_t p = r.pos[i];
+                if (out_pos) out_pos[i] = p;
+                if (out_ids) out_ids[i] = ids_[p];
+                out_scores[i] = r.score[i];
+            }
+            *out_n = k_eff;
+            set_last_path(PATH_FAST);
+            return OK;
+        }
+        // ties at the cut or a failed bound: fall through to the exact kernels
+    }
+
+    std::vector<uint32_t> pos;
+    std::vector<double> scores;
+    VL_TRY(run_exact(ws, metric, n, k_eff, &pos, &scores));
+    for (uint64_t i = 0; i < k_eff; ++i) {
+        if (out_pos) out_pos[i] = pos[i];
+        if (out_ids) out_ids[i] = ids_[pos[i]];
+        out_scores[i] = scores[i];
+    }
+    *out_n = k_eff;
+    return OK;
+}
+
+int GpuFlatIndex::run_exact(Workspace* ws, int metric, uint64_t n, uint64_t k_eff, std::vector<uint32_t>* pos,
+                            std::vector<double>* scores) const
+{
+    hipStream_t st = ws->stream;
+    if (ws->scores_cap < n) {
+        if (ws->d_scores) (void)hipFree(ws->d_scores);
+        ws->d_scores = nullptr;
+        ws->scores_cap = 0;
+        const size_t cap = std::max<size_t>(n, 1024);
+        VL_TRY(dev_alloc(&ws->d_scores, cap));
+        ws->scores_cap = cap;
+    }
+    VL_HIP(hipMemsetAsync(ws->d_nan, 0, sizeof(uint32_t), st));
+    VL_HIP(launch_exact_scan(st, metric, d_master_, ws->d_q64, n, (uint32_t)dim_, ws->d_scores, ws->d_nan));
+    VL_HIP(hipMemcpyAsync(ws->h_nan, ws->d_nan, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    pos->resize(k_eff);
+    scores->resize(k_eff);
+
+    if (n == 1) {  // a 1-element sort never calls the comparator: even a NaN score is returned
+        VL_HIP(hipMemcpyAsync(scores->data(), ws->d_scores, sizeof(double), hipMemcpyDeviceToHost, st));
+        VL_HIP(hipStreamSynchronize(st));
+        (*pos)[0] = 0;
+        set_last_path(PATH_EXACT_SELECT);
+        return OK;
+    }
+
+    const int forced = force_path_.load();
+    const bool use_select = k_eff <= (uint64_t)KP && forced != PATH_EXACT_SORT;
+    if (use_select) {
+        VL_HIP(launch_exact_select(st, ws->d_scores, n, (uint32_t)k_eff, ws->d_partials64, ws->d_nan, ws->d_result));
+        VL_HIP(hipMemcpyAsync(ws->h_result, ws->d_result, sizeof(SearchResultBlock), hipMemcpyDeviceToHost, st));
+        VL_HIP(hipStreamSynchronize(st));
+    } else {
+        const uint64_t cap = sort_capacity_for(n);
+        if (ws->sort_cap < cap) {
+            if (ws->d_okeys) (void)hipFree(ws->d_okeys);
+            if (ws->d_opos) (void)hipFree(ws->d_opos);
+            ws->d_okeys = nullptr;
+            ws->d_opos = nullptr;
+            ws->sort_cap = 0;
+            VL_TRY(dev_alloc(&ws->d_okeys, cap));
+            VL_TRY(dev_alloc(&ws->d_opos, cap));
+            ws->sort_cap = cap;
+        }
+        if (ws->out_cap < k_eff) {
+            if (ws->d_out_pos) (void)hipFree(ws->d_out_pos);
+            if (ws->d_out_scores) (void)hipFree(ws->d_out_scores);
+            ws->d_out_pos = nullptr;
+            ws->d_out_scores = nullptr;
+            ws->out_cap = 0;
+            VL_TRY(dev_alloc(&ws->d_out_pos, k_eff));
+            VL_TRY(dev_alloc(&ws->d_out_scores, k_eff));
+            ws->out_cap = k_eff;
+        }
+        VL_HIP(launch_exact_sort(st, ws->d_scores, n, k_eff, ws->d_okeys, ws->d_opos, ws->d_out_pos,
+                                 ws->d_out_scores));
+        VL_HIP(hipMemcpyAsync(pos->data(), ws->d_out_pos, k_eff * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        VL_HIP(hipMemcpyAsync(scores->data(), ws->d_out_scores, k_eff * sizeof(double), hipMemcpyDeviceToHost, st));
+        VL_HIP(hipStreamSynchronize(st));
+    }
+    if (*ws->h_nan) {
+        // sort_by(|a, b| b.score.partial_cmp(&a.score).unwrap()) panics on a NaN (src/index/flat.rs:116)
+        set_last_error("NaN similarity score: the reference panics in partial_cmp().unwrap()");
+        return ERR_NAN_SCORE;
+    }
+    if (use_select) {
+        const SearchResultBlock& r = *ws->h_result;
+        if (r.n_out != k_eff) {
+            set_last_error("exact select returned an unexpected result count");
+            return ERR_DEVICE;
+        }
+        for (uint64_t i = 0; i < k_eff; ++i) {
+            (*pos)[i] = r.pos[i];
+            (*scores)[i] = r.score[i];
+        }
+        set_last_path(PATH_EXACT_SELECT);
+    } else {
+        set_last_path(PATH_EXACT_SORT);
+    }
+    return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// point lookups / export / clone
+// ---------------------------------------------------------------------------------------------
+int GpuFlatIndex::get_vector(uint64_t id, double* out) const
+{
+    if (!out && dim_) return ERR_INVALID_ARG;
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    auto it = std::find(ids_.begin(), ids_.end(), id);  // first match (src/index/flat.rs:129-131)
+    if (it == ids_.end()) return ERR_NOT_FOUND;
+    const uint64_t pos = (uint64_t)(it - ids_.begin());
+    if (dim_) {
+        VL_HIP(hipSetDevice(device_));
+        VL_HIP(hipMemcpy(out, d_master_ + pos * dim_, dim_ * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return OK;
+}
+
+int GpuFlatIndex::max_id(uint64_t* out) const
+{
+    if (!out) return ERR_INVALID_ARG;
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    if (ids_.empty()) return ERR_NOT_FOUND;
+    *out = *std::max_element(ids_.begin(), ids_.end());
+    return OK;
+}
+
+int GpuFlatIndex::export_rows(uint64_t* out_ids, double* out_values) const
+{
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    const uint64_t n = ids_.size();
+    if (n == 0) return OK;
+    if (!out_ids || (!out_values && dim_)) return ERR_INVALID_ARG;
+    std::memcpy(out_ids, ids_.data(), n * sizeof(uint64_t));
+    if (dim_) {
+        VL_HIP(hipSetDevice(device_));
+        VL_HIP(hipMemcpy(out_values, d_master_, n * dim_ * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return OK;
+}
+
+int GpuFlatIndex::clone(GpuFlatIndex** out) const
+{
+    if (!out) return ERR_INVALID_ARG;
+    *out = nullptr;
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    GpuFlatIndex* c = nullptr;
+    VL_TRY(create(dim_, device_, &c));
+    std::unique_ptr<GpuFlatIndex> guard(c);
+    if (!ids_.empty())
+        VL_TRY(c->add_bulk(ids_.data(), d_master_, ids_.size(), /*validate=*/false, /*values_on_device=*/true));
+    c->force_path_.store(force_path_.load());
+    *out = guard.release();
+    return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// HNSW distance callbacks (src/index/hnsw.rs:113-174)
+// ---------------------------------------------------------------------------------------------
+int GpuFlatIndex::hnsw_distances(const double* query, uint64_t q_len, int metric, const uint64_t* positions,
+                                 uint64_t m, uint64_t* out) const
+{
+    if (metric < 0 || metric > 3) return ERR_INVALID_ARG;
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    if (q_len != dim_) {
+        set_dim_mismatch(dim_, q_len);
+        set_last_error("Dimension mismatch: expected " + std::to_string(dim_) + ", got " + std::to_string(q_len));
+        return ERR_DIM_MISMATCH;
+    }
+    if (m == 0) return OK;
+    if (!positions || !out || (!query && dim_)) return ERR_INVALID_ARG;
+    const uint64_t n = ids_.size();
+    std::vector<uint32_t> p32(m);
+    for (uint64_t i = 0; i < m; ++i) {
+        if (positions[i] >= n) {
+            set_last_error("position out of range");
+            return ERR_NOT_FOUND;
+        }
+        p32[i] = (uint32_t)positions[i];
+    }
+    VL_HIP(hipSetDevice(device_));
+    Workspace* ws = acquire_ws();
+    if (!ws) return ERR_DEVICE;
+    struct Releaser {
+        const GpuFlatIndex* self;
+        Workspace* ws;
+        ~Releaser()
+        {
+            (void)hipStreamSynchronize(ws->stream);
+            self->release_ws(ws);
+        }
+    } rel{this, ws};
+    hipStream_t st = ws->stream;
+    if (ws->hn_cap < m) {
+        if (ws->d_positions) (void)hipFree(ws->d_positions);
+        if (ws->d_dists) (void)hipFree(ws->d_dists);
+        ws->d_positions = nullptr;
+        ws->d_dists = nullptr;
+        ws->hn_cap = 0;
+        const size_t cap = std::max<size_t>(m, 256);
+        VL_TRY(dev_alloc(&ws->d_positions, cap));
+        VL_TRY(dev_alloc(&ws->d_dists, cap));
+        ws->hn_cap = cap;
+    }
+    for (uint64_t i = 0; i < dim_; ++i) ws->h_q64[i] = query[i];
+    if (dim_) VL_HIP(hipMemcpyAsync(ws->d_q64, ws->h_q64, dim_ * sizeof(double), hipMemcpyHostToDevice, st));
+    VL_HIP(hipMemcpyAsync(ws->d_positions, p32.data(), m * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    VL_HIP(launch_hnsw_distances(st, metric, d_master_, ws->d_q64, (uint32_t)dim_, ws->d_positions, (uint32_t)m,
+                                 ws->d_dists));
+    VL_HIP(hipMemcpyAsync(out, ws->d_dists, m * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    VL_HIP(hipStreamSynchronize(st));
+    return OK;
+}
+
+}  // namespace vl

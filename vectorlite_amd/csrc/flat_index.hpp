@@ -1,0 +1,160 @@
+// flat_index.hpp -- C++ host side of the GPU flat index: the mirror of the reference's
+// `impl VectorIndex for FlatIndex` (src/index/flat.rs:60-135) above the HIP kernels.
+// The reference is compiled code (Rust, not buildable in this image), so the host layer is
+// C++; include/vectorlite_amd.h exposes it as the C ABI a Rust `impl VectorIndex` would bind.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace vl {
+
+// vl_status values (include/vectorlite_amd.h)
+enum Status : int {
+    OK = 0,
+    ERR_DIM_MISMATCH = 1,
+    ERR_DUP_ID = 2,
+    ERR_NOT_FOUND = 3,
+    ERR_METRIC_MISMATCH = 4,
+    ERR_NAN_SCORE = 5,
+    ERR_DEVICE = 6,
+    ERR_OOM = 7,
+    ERR_INVALID_ARG = 8,
+};
+
+enum Path : int { PATH_NONE = 0, PATH_FAST = 1, PATH_EXACT_SELECT = 2, PATH_EXACT_SORT = 3 };
+
+// thread-local diagnostics (vl_last_error & friends)
+void set_last_error(const std::string& msg);
+const char* last_error();
+void set_dim_mismatch(uint64_t expected, uint64_t actual);
+void get_dim_mismatch(uint64_t* expected, uint64_t* actual);
+void set_last_path(int p);
+int last_path();
+
+// Per-search scratch: one HIP stream plus device/pinned buffers.  Searches are re-entrant
+// (the reference searches under RwLock::read, src/client.rs:398): each call borrows one.
+struct Workspace {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    float* d_q32 = nullptr;
+    double* d_q64 = nullptr;
+    float* h_q32 = nullptr;   // pinned
+    double* h_q64 = nullptr;  // pinned
+    size_t q_cap = 0;
+    Cand32* d_partials = nullptr;
+    Cand64* d_partials64 = nullptr;
+    SearchResultBlock* d_result = nullptr;
+    SearchResultBlock* h_result = nullptr;  // pinned
+    uint32_t* d_nan = nullptr;
+    uint32_t* h_nan = nullptr;  // pinned
+    // exact path (lazy)
+    double* d_scores = nullptr;
+    size_t scores_cap = 0;
+    uint64_t* d_okeys = nullptr;
+    uint32_t* d_opos = nullptr;
+    size_t sort_cap = 0;
+    uint32_t* d_out_pos = nullptr;
+    double* d_out_scores = nullptr;
+    size_t out_cap = 0;
+    // hnsw distances (lazy)
+    uint32_t* d_positions = nullptr;
+    uint64_t* d_dists = nullptr;
+    size_t hn_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    ~Workspace();
+};
+
+class GpuFlatIndex {
+public:
+    // FlatIndex::new(dim, Vec::new())
+    static int create(uint64_t dim, int device, GpuFlatIndex** out);
+    ~GpuFlatIndex();
+
+    // trait VectorIndex (src/lib.rs:224-245)
+    int add(uint64_t id, const double* values, uint64_t len);
+    int add_bulk(const uint64_t* ids, const double* values, uint64_t n, bool validate, bool values_on_device);
+    int remove(uint64_t id);  // `delete`
+    int search(const double* query, uint64_t q_len, uint64_t k, int metric, uint64_t* out_pos,
+               uint64_t* out_ids, double* out_scores, uint64_t* out_n) const;
+    uint64_t len() const;
+    bool is_empty() const { return len() == 0; }
+    uint64_t dimension() const { return dim_; }
+    int get_vector(uint64_t id, double* out) const;
+    int max_id(uint64_t* out) const;
+
+    int clone(GpuFlatIndex** out) const;
+    int reserve(uint64_t n_rows);
+    int export_rows(uint64_t* out_ids, double* out_values) const;
+    int hnsw_distances(const double* query, uint64_t q_len, int metric, const uint64_t* positions, uint64_t m,
+                       uint64_t* out) const;
+
+    void force_path(int p) { force_path_.store(p); }
+    void profile_enable(bool on);
+    void profile_read(uint64_t* n, double* ms, uint64_t* bytes);
+    int device() const { return device_; }
+
+private:
+    GpuFlatIndex(uint64_t dim, int device);
+    int ensure_capacity(uint64_t rows);  // caller holds the unique lock
+    int ingest_range(uint64_t first, uint64_t n);
+    int remove_position(uint64_t pos);
+    void rebuild_id_counts() const;
+    Workspace* acquire_ws() const;
+    void release_ws(Workspace* ws) const;
+    int prepare_ws(Workspace* ws) const;
+    int search_locked(Workspace* ws, const double* query, uint64_t k_eff, int metric, uint64_t* out_pos,
+                      uint64_t* out_ids, double* out_scores, uint64_t* out_n) const;
+    int run_exact(Workspace* ws, int metric, uint64_t n, uint64_t k_eff, std::vector<uint32_t>* pos,
+                  std::vector<double>* scores) const;
+
+    const uint64_t dim_;
+    const uint32_t ld_;  // slab row stride in floats: dim rounded up to 4 (16-byte vector loads)
+    const int device_;
+
+    mutable std::shared_mutex mu_;  // search: shared; add/delete: unique
+    // device storage
+    double* d_master_ = nullptr;  // [cap, dim] f64: exact rows
+    float* d_slab_ = nullptr;     // [cap, ld]  f32: what the scan streams
+    float* d_inv_norm_ = nullptr; // [cap]      f32: 1/|row|, 0 for zero rows
+    uint8_t* d_flags_ = nullptr;  // [cap]
+    IngestStats* d_stats_ = nullptr;
+    uint64_t cap_ = 0;
+    hipStream_t mut_stream_ = nullptr;
+    void* d_bounce_ = nullptr;  // delete compaction buffer
+    size_t bounce_bytes_ = 0;
+
+    // host bookkeeping
+    std::vector<uint64_t> ids_;        // position -> id (insertion order)
+    std::vector<uint8_t> row_flags_;   // position -> ROW_* flags
+    uint64_t n_out_of_domain_ = 0;
+    double max_row_norm_ = 0.0;        // upper bound over in-domain rows ever stored
+    mutable std::unordered_map<uint64_t, uint32_t> id_counts_;  // id -> multiplicity (lazy)
+    mutable bool id_counts_valid_ = true;
+
+    // workspace pool
+    mutable std::mutex ws_mu_;
+    mutable std::vector<Workspace*> ws_free_;
+    mutable std::vector<std::unique_ptr<Workspace>> ws_all_;
+
+    std::atomic<int> force_path_{0};
+    std::atomic<bool> profile_{false};
+    mutable std::mutex prof_mu_;
+    mutable uint64_t prof_n_ = 0;
+    mutable double prof_ms_ = 0.0;
+    mutable uint64_t prof_bytes_ = 0;
+};
+
+}  // namespace vl

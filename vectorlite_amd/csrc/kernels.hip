@@ -1,0 +1,993 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the distance-scan hot path.
+//
+// Reference semantics being reproduced (paths relative to /root/reference):
+//   FlatIndex::search            src/index/flat.rs:98-119   (score every row, stable sort desc, truncate k)
+//   SimilarityMetric::calculate  src/lib.rs:380-391, :425-572 (f64, strict index order, no FMA)
+//   HNSW Metric::distance -> u64 src/index/hnsw.rs:113-174
+//
+// Design (DESIGN.md has the full argument):
+//   * K1 k_scan: streams the [N, ld] f32 slab once. G lanes share a row, every lane issues 16-byte
+//     non-temporal loads straight to VGPRs (no LDS round trip: nothing is reused), several row groups
+//     in flight per wave; partial sums are reduced with cross-lane shuffles; each wave keeps a sorted
+//     top-64 candidate list, ONE ENTRY PER LANE, updated by ballot/shuffle only when a row beats the
+//     wave's current 64th key.  HBM-bound: 4*ld algorithmic bytes per row.
+//   * K2 k_merge_finalize: merges the per-workgroup lists (bitonic merges in registers/LDS), then
+//     RE-SCORES the 64 candidates from the f64 master rows in the reference's exact operation order
+//     (separate multiply and add, index order, this file is compiled with -ffp-contract=off), ranks
+//     them by (score desc, position asc) and proves -- with a rigorous f32 error bound on every row
+//     that was NOT kept -- that no other row can reach the k-th score.  If the proof fails (ties at
+//     the cut, adversarial data) the host re-runs the query on the exact kernels below.
+//   * Exact path: k_exact_scan (reference-order f64 score of every row, LDS-transposed so global
+//     reads stay coalesced) + k_select64 / bitonic sort on (score desc, position asc).
+//   * k_hnsw_dist: the four HNSW distance callbacks, f64 reference order, Rust `as u64` semantics.
+#include "kernels.hpp"
+
+#include <math.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+namespace vl {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+// Total order of candidates: higher key first, then lower storage position (the reference's
+// stable sort keeps insertion order on ties: src/index/flat.rs:116, src/client.rs:665-667).
+template <typename K>
+__device__ __forceinline__ bool better(K ka, uint32_t pa, K kb, uint32_t pb)
+{
+    return ka > kb || (ka == kb && pa < pb);
+}
+
+template <typename K>
+__device__ __forceinline__ K neg_inf();
+template <>
+__device__ __forceinline__ float neg_inf<float>() { return -INFINITY; }
+template <>
+__device__ __forceinline__ double neg_inf<double>() { return -(double)INFINITY; }
+
+// ---------------------------------------------------------------------------------------------
+// Sorted top-64 list held one entry per lane (lane 0 = best).
+// ---------------------------------------------------------------------------------------------
+template <typename K>
+struct TopList {
+    K key;
+    uint32_t pos;
+    K thr_key;  // wave-uniform copy of lane 63's entry
+    uint32_t thr_pos;
+
+    __device__ __forceinline__ void init()
+    {
+        key = neg_inf<K>();
+        pos = POS_SENTINEL;
+        thr_key = neg_inf<K>();
+        thr_pos = POS_SENTINEL;
+    }
+
+    __device__ __forceinline__ void insert(K k, uint32_t p)
+    {
+        // entries that stay in front of (k, p): a prefix of the lanes because the list is sorted
+        const unsigned long long ahead = __ballot(better<K>(key, pos, k, p));
+        const int idx = __popcll(ahead);
+        const K upk = __shfl_up(key, 1);
+        const uint32_t upp = __shfl_up(pos, 1);
+        const int lane = lane_id();
+        if (lane == idx) {
+            key = k;
+            pos = p;
+        } else if (lane > idx) {
+            key = upk;
+            pos = upp;
+        }
+        thr_key = __shfl(key, WAVE - 1);
+        thr_pos = __shfl(pos, WAVE - 1);
+    }
+
+    // Every lane may offer one (key, pos); lanes are drained in lane order.
+    __device__ __forceinline__ void offer(K k, uint32_t p, bool active)
+    {
+        unsigned long long m = __ballot(active && better<K>(k, p, thr_key, thr_pos));
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            insert(__shfl(k, src), __shfl(p, src));
+        }
+    }
+
+    // Merge with another sorted list handed over REVERSED (lane i holds its entry 63-i):
+    // the element-wise best is a bitonic sequence holding the 64 best of the union.
+    __device__ __forceinline__ void merge_reversed(K ok, uint32_t op)
+    {
+        if (better<K>(ok, op, key, pos)) {
+            key = ok;
+            pos = op;
+        }
+        const int lane = lane_id();
+#pragma unroll
+        for (int o = WAVE / 2; o >= 1; o >>= 1) {
+            const K k2 = __shfl_xor(key, o);
+            const uint32_t p2 = __shfl_xor(pos, o);
+            const bool lower = (lane & o) == 0;
+            const bool other_better = better<K>(k2, p2, key, pos);
+            if (lower == other_better) {
+                key = k2;
+                pos = p2;
+            }
+        }
+        thr_key = __shfl(key, WAVE - 1);
+        thr_pos = __shfl(pos, WAVE - 1);
+    }
+};
+
+// Tree-merge the NW sorted wave lists of a workgroup through LDS; wave 0 ends with the result.
+template <typename K, typename C, int NW>
+__device__ __forceinline__ void block_merge(TopList<K>& L, C* sh /* [NW][64] */)
+{
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    sh[wave * WAVE + lane].key = L.key;
+    sh[wave * WAVE + lane].pos = L.pos;
+    __syncthreads();
+#pragma unroll
+    for (int s = NW / 2; s >= 1; s >>= 1) {
+        if (wave < s) {
+            const C o = sh[(wave + s) * WAVE + (WAVE - 1 - lane)];
+            L.merge_reversed(o.key, o.pos);
+            sh[wave * WAVE + lane].key = L.key;
+            sh[wave * WAVE + lane].pos = L.pos;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: f32 slab scan
+// ---------------------------------------------------------------------------------------------
+template <int METRIC>
+__device__ __forceinline__ float acc4(float a, const f32x4 x, const f32x4 q)
+{
+    if (METRIC == COSINE || METRIC == DOT) {
+        a = fmaf(x.x, q.x, a);
+        a = fmaf(x.y, q.y, a);
+        a = fmaf(x.z, q.z, a);
+        a = fmaf(x.w, q.w, a);
+    } else if (METRIC == EUCLIDEAN) {
+        const float d0 = x.x - q.x, d1 = x.y - q.y, d2 = x.z - q.z, d3 = x.w - q.w;
+        a = fmaf(d0, d0, a);
+        a = fmaf(d1, d1, a);
+        a = fmaf(d2, d2, a);
+        a = fmaf(d3, d3, a);
+    } else {
+        a += fabsf(x.x - q.x);
+        a += fabsf(x.y - q.y);
+        a += fabsf(x.z - q.z);
+        a += fabsf(x.w - q.w);
+    }
+    return a;
+}
+
+// Scan key (larger = better) from the reduced row sum.  Cosine is ranked by dot * (1/|row|): the
+// 1/|query| factor is the same positive number for every row.  Euclidean/Manhattan are ranked by
+// the negated sum: 1/(1+sqrt(s)) and 1/(1+s) are monotone in s, so the scan needs no sqrt/division.
+template <int METRIC>
+__device__ __forceinline__ float scan_key(float sum, float inv_norm)
+{
+    if (METRIC == COSINE) return sum * inv_norm;
+    if (METRIC == DOT) return sum;
+    return -sum;
+}
+
+template <int G>
+__device__ __forceinline__ float group_reduce(float a)
+{
+#pragma unroll
+    for (int o = G / 2; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+    return a;
+}
+
+// Specialised: ld4 == G * VPL float4 per row, U row groups in flight per wave.
+template <int METRIC, int G, int VPL, int U>
+__global__ __launch_bounds__(256) void k_scan(const f32x4* __restrict__ slab, const float* __restrict__ inv_norm,
+                                              const f32x4* __restrict__ q, uint32_t n, Cand32* __restrict__ out)
+{
+    constexpr int RPS = WAVE / G;  // rows per step of one wave
+    constexpr uint32_t LD4 = G * VPL;
+    __shared__ Cand32 sh[4 * WAVE];
+
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int g = lane / G, c = lane % G;
+
+    f32x4 qv[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) qv[j] = q[c + G * j];
+
+    const uint32_t n_steps = (n + RPS - 1) / RPS;
+    const uint32_t n_waves = gridDim.x * 4;
+    const uint32_t wave_global = blockIdx.x * 4 + wave;
+
+    TopList<float> L;
+    L.init();
+
+    for (uint32_t s0 = wave_global; s0 < n_steps; s0 += n_waves * U) {
+        f32x4 x[U][VPL];
+        uint32_t row[U];
+        float inv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t s = s0 + (uint32_t)u * n_waves;
+            row[u] = s < n_steps ? s * RPS + g : n;  // n marks "no row"
+            const uint32_t r = row[u] < n ? row[u] : n - 1;  // clamp: loads stay in bounds
+            const f32x4* p = slab + (size_t)r * LD4 + c;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) x[u][j] = __builtin_nontemporal_load(p + G * j);
+            inv[u] = 1.0f;
+            if (METRIC == COSINE) inv[u] = inv_norm[r];  // issued with the row loads, not after them
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float a = 0.0f;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) a = acc4<METRIC>(a, x[u][j], qv[j]);
+            a = group_reduce<G>(a);
+            const float key = scan_key<METRIC>(a, inv[u]);
+            L.offer(key, row[u], row[u] < n && c == 0);
+        }
+    }
+
+    block_merge<float, Cand32, 4>(L, sh);
+    if (wave == 0) {
+        Cand32 e;
+        e.key = L.key;
+        e.pos = L.pos;
+        out[(size_t)blockIdx.x * KP + lane] = e;
+    }
+}
+
+// Generic: any ld4 (float4 per row), G = lanes per row (power of two <= 64).
+template <int METRIC, int G>
+__global__ __launch_bounds__(256) void k_scan_generic(const f32x4* __restrict__ slab,
+                                                      const float* __restrict__ inv_norm,
+                                                      const f32x4* __restrict__ q, uint32_t n, uint32_t ld4,
+                                                      Cand32* __restrict__ out)
+{
+    constexpr int RPS = WAVE / G;
+    __shared__ Cand32 sh[4 * WAVE];
+
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int g = lane / G, c = lane % G;
+
+    const uint32_t n_steps = (n + RPS - 1) / RPS;
+    const uint32_t n_waves = gridDim.x * 4;
+
+    TopList<float> L;
+    L.init();
+
+    for (uint32_t s = blockIdx.x * 4 + wave; s < n_steps; s += n_waves) {
+        const uint32_t row = s * RPS + g;
+        const bool valid = row < n;
+        const uint32_t r = valid ? row : n - 1;
+        const f32x4* p = slab + (size_t)r * ld4;
+        float a = 0.0f;
+        for (uint32_t j = c; j < ld4; j += G) a = acc4<METRIC>(a, p[j], q[j]);
+        a = group_reduce<G>(a);
+        float inv = 1.0f;
+        if (METRIC == COSINE) inv = inv_norm[r];
+        L.offer(scan_key<METRIC>(a, inv), row, valid && c == 0);
+    }
+
+    block_merge<float, Cand32, 4>(L, sh);
+    if (wave == 0) {
+        Cand32 e;
+        e.key = L.key;
+        e.pos = L.pos;
+        out[(size_t)blockIdx.x * KP + lane] = e;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reference-order f64 arithmetic (this TU is built with -ffp-contract=off: `a += x * y` is one
+// rounded multiply followed by one rounded add, like rustc's output for src/lib.rs:425-572).
+// ---------------------------------------------------------------------------------------------
+template <int METRIC>
+struct Acc64 {
+    double a, b, c;
+    __device__ __forceinline__ void init()
+    {
+        // cosine folds from (0.0, 0.0, 0.0) (src/lib.rs:428); the `.sum::<f64>()` metrics fold from
+        // the float additive identity -0.0 (core::iter::Sum, rustc >= 1.83; crate edition 2024).
+        a = (METRIC == COSINE) ? 0.0 : -0.0;
+        b = 0.0;
+        c = 0.0;
+    }
+    __device__ __forceinline__ void step(double x, double y)
+    {
+        if (METRIC == COSINE) {
+            a += x * y;
+            b += x * x;
+            c += y * y;
+        } else if (METRIC == EUCLIDEAN) {
+            const double d = x - y;
+            a += d * d;
+        } else if (METRIC == MANHATTAN) {
+            a += fabs(x - y);
+        } else {
+            a += x * y;
+        }
+    }
+    // SimilarityMetric::calculate's return value
+    __device__ __forceinline__ double score() const
+    {
+        if (METRIC == COSINE) {
+            const double na = sqrt(b), nb = sqrt(c);
+            if (na == 0.0 || nb == 0.0) return 0.0;
+            return a / (na * nb);
+        }
+        if (METRIC == EUCLIDEAN) return 1.0 / (1.0 + sqrt(a));
+        if (METRIC == MANHATTAN) return 1.0 / (1.0 + a);
+        return a;
+    }
+};
+
+// Rust `f64 as u64`: truncation toward zero, saturating, NaN -> 0.
+__device__ __forceinline__ unsigned long long rust_as_u64(double v)
+{
+    if (!(v > 0.0)) return 0ull;
+    if (v >= 18446744073709551616.0) return ~0ull;
+    return (unsigned long long)v;
+}
+
+// impl Metric<Vec<f64>>::distance (src/index/hnsw.rs:113-174)
+template <int METRIC>
+__device__ __forceinline__ unsigned long long hnsw_quantise(const Acc64<METRIC>& A)
+{
+    if (METRIC == EUCLIDEAN) return rust_as_u64(sqrt(A.a) * 1000.0);
+    if (METRIC == COSINE) {
+        const double na = sqrt(A.b), nb = sqrt(A.c);
+        if (na == 0.0 || nb == 0.0) return 1000ull;
+        const double cosine_sim = A.a / (na * nb);
+        return rust_as_u64((1.0 - cosine_sim) * 1000.0);
+    }
+    if (METRIC == MANHATTAN) return rust_as_u64(A.a * 1000.0);
+    double d = A.a;  // f64::clamp(-1000, 1000): NaN stays NaN
+    if (d < -1000.0) d = -1000.0;
+    if (d > 1000.0) d = 1000.0;
+    return rust_as_u64(1000.0 - d);
+}
+
+// Rescore up to 64 rows (positions in LDS) against the query: global reads are coalesced along the
+// row (all threads load a [64][CH] f64 tile into LDS), then lanes 0..63 of wave 0 each walk one
+// row's chunk in index order.  Row stride CH+1 doubles keeps the per-lane ds_read_b64 conflict-free.
+constexpr int RESCORE_CH = 96;
+
+template <int METRIC, int NTHREADS>
+__device__ __forceinline__ void rescore_rows(const double* __restrict__ master, const double* __restrict__ q64,
+                                             uint32_t dim, const uint32_t* sh_pos, int n_rows,
+                                             double (*tile)[RESCORE_CH + 1], double* qtile, Acc64<METRIC>& A)
+{
+    const int tid = threadIdx.x;
+    A.init();
+    for (uint32_t c0 = 0; c0 < dim; c0 += RESCORE_CH) {
+        const uint32_t cw = (dim - c0) < (uint32_t)RESCORE_CH ? (dim - c0) : (uint32_t)RESCORE_CH;
+        __syncthreads();  // previous chunk fully consumed
+        for (int idx = tid; idx < KP * RESCORE_CH; idx += NTHREADS) {
+            const int r = idx / RESCORE_CH, cc = idx % RESCORE_CH;
+            if (r < n_rows && (uint32_t)cc < cw) tile[r][cc] = master[(size_t)sh_pos[r] * dim + c0 + cc];
+        }
+        if (tid < RESCORE_CH && (uint32_t)tid < cw) qtile[tid] = q64[c0 + tid];
+        __syncthreads();
+        if (tid < n_rows) {
+            for (uint32_t cc = 0; cc < cw; ++cc) A.step(tile[tid][cc], qtile[cc]);
+        }
+    }
+}
+
+// Upper bound B on the REFERENCE f64 score of any row whose f32 scan key is <= t, for in-domain data
+// (finite, |v| <= 2^40, row norms 0 or >= 2^-40).  u = 2^-24, n = padded dim, R = max row norm,
+// Q = |query|.  Derivation in DESIGN.md ("Exactness bound"); every u-term carries a 2x safety factor.
+template <int METRIC>
+__device__ __forceinline__ double bound_for_key(float t_key, uint32_t n, double R, double Q)
+{
+    const double u = 5.9604644775390625e-08;  // 2^-24
+    const double nn = (double)n;
+    const double t = (double)t_key;
+    if (METRIC == COSINE) {
+        if (!(Q > 0.0)) return (double)INFINITY;
+        return t / Q + 2.0 * (nn + 4.0) * u + 1e-12;
+    }
+    if (METRIC == DOT) {
+        return t + 2.0 * (nn + 2.0) * u * R * Q + 1e-12 * (1.0 + R * Q);
+    }
+    const double ts = t < 0.0 ? -t : 0.0;  // key = -sum
+    double d_lo;
+    if (METRIC == EUCLIDEAN) {
+        d_lo = sqrt(ts) * (1.0 - 2.0 * (nn + 2.0) * u) - 4.0 * u * (R + Q);
+    } else {
+        d_lo = ts * (1.0 - 2.0 * (nn + 2.0) * u) - 4.0 * u * sqrt(nn) * (R + Q);
+    }
+    if (!(d_lo > 0.0)) d_lo = 0.0;
+    return (1.0 / (1.0 + d_lo * (1.0 - 1e-12))) * (1.0 + 1e-15);
+}
+
+// K2: merge partial lists, rescore, rank, bound-check.  One workgroup of 1024 threads.
+template <int METRIC>
+__global__ __launch_bounds__(1024) void k_merge_finalize(const Cand32* __restrict__ partials, int n_lists,
+                                                         const double* __restrict__ master,
+                                                         const double* __restrict__ q64, uint32_t dim,
+                                                         uint32_t ld, uint64_t n_rows, uint32_t k, double R,
+                                                         double Q, SearchResultBlock* __restrict__ out)
+{
+    constexpr int NW = 16;
+    __shared__ Cand32 sh_lists[NW * WAVE];
+    __shared__ double tile[KP][RESCORE_CH + 1];
+    __shared__ double qtile[RESCORE_CH];
+    __shared__ uint32_t sh_pos[KP];
+    __shared__ float sh_key[KP];
+    __shared__ double sh_score[KP];
+    __shared__ int sh_ncand;
+
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+
+    // phase 1: 16 waves fold the partial lists, then a 4-level bitonic tree merge
+    TopList<float> L;
+    L.init();
+    for (int l = wave; l < n_lists; l += NW) {
+        const Cand32 e = partials[(size_t)l * KP + lane];
+        L.offer(e.key, e.pos, e.pos != POS_SENTINEL);
+    }
+    block_merge<float, Cand32, NW>(L, sh_lists);
+    if (wave == 0) {
+        sh_pos[lane] = L.pos;
+        sh_key[lane] = L.key;
+        const unsigned long long real = __ballot(L.pos != POS_SENTINEL);
+        if (lane == 0) sh_ncand = __popcll(real);
+    }
+    __syncthreads();
+    const int n_cand = sh_ncand;
+
+    // phase 2: exact f64 rescoring of the candidates
+    Acc64<METRIC> A;
+    rescore_rows<METRIC, 1024>(master, q64, dim, sh_pos, n_cand, tile, qtile, A);
+
+    // phase 3: rank by (score desc, pos asc), bound check, emit
+    if (wave == 0) {
+        const bool valid = lane < n_cand;
+        const double sc = valid ? A.score() : 0.0;
+        const uint32_t my_pos = sh_pos[lane];
+        sh_score[lane] = sc;
+        __builtin_amdgcn_wave_barrier();
+        const bool any_nan = __ballot(valid && sc != sc) != 0ull;
+        int rank = 0;
+        for (int j = 0; j < n_cand; ++j) {
+            const double sj = sh_score[j];
+            const uint32_t pj = sh_pos[j];
+            rank += (sj > sc || (sj == sc && pj < my_pos)) ? 1 : 0;
+        }
+        const uint32_t k_eff = (uint64_t)k < n_rows ? k : (uint32_t)n_rows;
+        uint32_t flags = 0;
+        if (any_nan) flags |= RESULT_HAS_NAN | RESULT_NEEDS_EXACT;
+        if (n_rows > (uint64_t)KP) {
+            // rows outside the candidate list exist: all of them have scan key <= the 64th key
+            if (n_cand < KP) {
+                flags |= RESULT_NEEDS_EXACT;  // keys were not finite: outside the fast-path domain
+            } else {
+                const double B = bound_for_key<METRIC>(sh_key[KP - 1], ld, R, Q);
+                // score of the entry ranked k_eff-1
+                const unsigned long long at_cut = __ballot(valid && rank == (int)k_eff - 1);
+                double s_cut = 0.0;
+                if (at_cut) s_cut = __shfl(sc, __ffsll((long long)at_cut) - 1);
+                if (!at_cut || !(s_cut > B)) flags |= RESULT_NEEDS_EXACT;
+            }
+        }
+        if (valid && rank < (int)k_eff) {
+            out->pos[rank] = my_pos;
+            out->score[rank] = sc;
+        }
+        if (lane == 0) {
+            out->n_out = k_eff;
+            out->flags = flags;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact path
+// ---------------------------------------------------------------------------------------------
+constexpr int EX_ROWS = 256;  // rows per workgroup tile (one per thread)
+constexpr int EX_CH = 16;     // columns per chunk: 128 B of each row = one full line
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void k_exact_scan(const double* __restrict__ master,
+                                                    const double* __restrict__ q64, uint64_t n, uint32_t dim,
+                                                    double* __restrict__ scores, uint32_t* __restrict__ nan_flag)
+{
+    __shared__ double tile[EX_ROWS][EX_CH + 1];
+    __shared__ double qtile[EX_CH];
+    const int tid = threadIdx.x;
+    const uint64_t n_tiles = (n + EX_ROWS - 1) / EX_ROWS;
+    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint64_t row0 = t * EX_ROWS;
+        const uint64_t rows_here = (n - row0) < (uint64_t)EX_ROWS ? (n - row0) : (uint64_t)EX_ROWS;
+        Acc64<METRIC> A;
+        A.init();
+        for (uint32_t c0 = 0; c0 < dim; c0 += EX_CH) {
+            const uint32_t cw = (dim - c0) < (uint32_t)EX_CH ? (dim - c0) : (uint32_t)EX_CH;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < EX_CH; ++i) {
+                const int idx = tid + i * 256;
+                const int r = idx / EX_CH, cc = idx % EX_CH;
+                if ((uint64_t)r < rows_here && (uint32_t)cc < cw)
+                    tile[r][cc] = master[(row0 + r) * dim + c0 + cc];
+            }
+            if (tid < EX_CH && (uint32_t)tid < cw) qtile[tid] = q64[c0 + tid];
+            __syncthreads();
+            if ((uint64_t)tid < rows_here) {
+                for (uint32_t cc = 0; cc < cw; ++cc) A.step(tile[tid][cc], qtile[cc]);
+            }
+        }
+        if ((uint64_t)tid < rows_here) {
+            const double sc = A.score();
+            scores[row0 + tid] = sc;
+            if (sc != sc) atomicOr(nan_flag, 1u);
+        }
+    }
+}
+
+// top-64 of scores[] by (score desc, pos asc): per-wave lists, then per-workgroup merge
+__global__ __launch_bounds__(256) void k_select64(const double* __restrict__ scores, uint32_t n,
+                                                  Cand64* __restrict__ out)
+{
+    __shared__ Cand64 sh[4 * WAVE];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const uint32_t n_steps = (n + WAVE - 1) / WAVE;
+    const uint32_t n_waves = gridDim.x * 4;
+    TopList<double> L;
+    L.init();
+    for (uint32_t s = blockIdx.x * 4 + wave; s < n_steps; s += n_waves) {
+        const uint32_t row = s * WAVE + lane;
+        const bool valid = row < n;
+        const double sc = valid ? scores[row] : 0.0;
+        L.offer(sc, row, valid);
+    }
+    block_merge<double, Cand64, 4>(L, sh);
+    if (wave == 0) {
+        Cand64 e;
+        e.key = L.key;
+        e.pos = L.pos;
+        e.pad = 0;
+        out[(size_t)blockIdx.x * KP + lane] = e;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_merge64_emit(const Cand64* __restrict__ partials, int n_lists,
+                                                       uint64_t n_rows, uint32_t k,
+                                                       const uint32_t* __restrict__ nan_flag,
+                                                       SearchResultBlock* __restrict__ out)
+{
+    constexpr int NW = 16;
+    __shared__ Cand64 sh[NW * WAVE];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    TopList<double> L;
+    L.init();
+    for (int l = wave; l < n_lists; l += NW) {
+        const Cand64 e = partials[(size_t)l * KP + lane];
+        L.offer(e.key, e.pos, e.pos != POS_SENTINEL);
+    }
+    block_merge<double, Cand64, NW>(L, sh);
+    if (wave == 0) {
+        const uint32_t k_eff = (uint64_t)k < n_rows ? k : (uint32_t)n_rows;
+        if ((uint32_t)lane < k_eff) {
+            out->pos[lane] = L.pos;
+            out->score[lane] = L.key;
+        }
+        if (lane == 0) {
+            out->n_out = k_eff;
+            out->flags = (*nan_flag) ? RESULT_HAS_NAN : 0u;
+        }
+    }
+}
+
+// ---- device-wide bitonic sort on (score desc, pos asc) for k > 64 ------------------------------
+// okey: u64 whose ASCENDING unsigned order is the DESCENDING order of the score (-0.0 == +0.0).
+__device__ __forceinline__ unsigned long long desc_key(double s)
+{
+    s = s + 0.0;  // -0.0 -> +0.0: partial_cmp treats them as equal
+    unsigned long long b = (unsigned long long)__double_as_longlong(s);
+    const unsigned long long asc = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    return ~asc;
+}
+
+__global__ void k_sort_init(const double* __restrict__ scores, uint64_t n, uint64_t cap,
+                            unsigned long long* __restrict__ okeys, uint32_t* __restrict__ opos)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < cap;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        if (i < n) {
+            okeys[i] = desc_key(scores[i]);
+            opos[i] = (uint32_t)i;
+        } else {
+            okeys[i] = ~0ull;
+            opos[i] = POS_SENTINEL;
+        }
+    }
+}
+
+__device__ __forceinline__ bool pair_greater(unsigned long long ka, uint32_t pa, unsigned long long kb, uint32_t pb)
+{
+    return ka > kb || (ka == kb && pa > pb);
+}
+
+constexpr int SORT_LOCAL = 2048;  // elements sorted in LDS by one 1024-thread workgroup
+
+// All stages with j < SORT_LOCAL for k in [k_lo, k_hi] (k_lo == k_hi > SORT_LOCAL: tail of one k).
+__global__ __launch_bounds__(1024) void k_bitonic_local(unsigned long long* __restrict__ okeys,
+                                                        uint32_t* __restrict__ opos, uint64_t k_lo, uint64_t k_hi)
+{
+    __shared__ unsigned long long sk[SORT_LOCAL];
+    __shared__ uint32_t sp[SORT_LOCAL];
+    const uint64_t base = (uint64_t)blockIdx.x * SORT_LOCAL;
+    const int tid = threadIdx.x;
+    sk[tid] = okeys[base + tid];
+    sp[tid] = opos[base + tid];
+    sk[tid + 1024] = okeys[base + tid + 1024];
+    sp[tid + 1024] = opos[base + tid + 1024];
+    __syncthreads();
+    for (uint64_t k = k_lo; k <= k_hi; k <<= 1) {
+        uint64_t j = (k >> 1) < (uint64_t)(SORT_LOCAL >> 1) ? (k >> 1) : (uint64_t)(SORT_LOCAL >> 1);
+        for (; j >= 1; j >>= 1) {
+            // thread t handles the pair (i, i ^ j) with i the t-th index whose bit j is clear
+            const uint32_t jj = (uint32_t)j;
+            const uint32_t i = ((tid & ~(jj - 1)) << 1) | (tid & (jj - 1));
+            const uint32_t l = i | jj;
+            const bool up = (((base + i) & k) == 0);
+            const unsigned long long ka = sk[i], kb = sk[l];
+            const uint32_t pa = sp[i], pb = sp[l];
+            const bool gt = pair_greater(ka, pa, kb, pb);
+            if (gt == up) {
+                sk[i] = kb;
+                sp[i] = pb;
+                sk[l] = ka;
+                sp[l] = pa;
+            }
+            __syncthreads();
+        }
+    }
+    okeys[base + tid] = sk[tid];
+    opos[base + tid] = sp[tid];
+    okeys[base + tid + 1024] = sk[tid + 1024];
+    opos[base + tid + 1024] = sp[tid + 1024];
+}
+
+__global__ void k_bitonic_global(unsigned long long* __restrict__ okeys, uint32_t* __restrict__ opos,
+                                 uint64_t cap, uint64_t j, uint64_t k)
+{
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < (cap >> 1);
+         t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const uint64_t l = i | j;
+        const bool up = ((i & k) == 0);
+        const unsigned long long ka = okeys[i], kb = okeys[l];
+        const uint32_t pa = opos[i], pb = opos[l];
+        if (pair_greater(ka, pa, kb, pb) == up) {
+            okeys[i] = kb;
+            opos[i] = pb;
+            okeys[l] = ka;
+            opos[l] = pa;
+        }
+    }
+}
+
+__global__ void k_sort_emit(const uint32_t* __restrict__ opos, const double* __restrict__ scores, uint64_t k,
+                            uint32_t* __restrict__ out_pos, double* __restrict__ out_scores)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < k;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t p = opos[i];
+        out_pos[i] = p;
+        out_scores[i] = scores[p];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// HNSW distance callbacks
+// ---------------------------------------------------------------------------------------------
+template <int METRIC>
+__global__ __launch_bounds__(256) void k_hnsw_dist(const double* __restrict__ master,
+                                                   const double* __restrict__ q64, uint32_t dim,
+                                                   const uint32_t* __restrict__ positions, uint32_t m,
+                                                   unsigned long long* __restrict__ out)
+{
+    __shared__ double tile[KP][RESCORE_CH + 1];
+    __shared__ double qtile[RESCORE_CH];
+    __shared__ uint32_t sh_pos[KP];
+    const uint32_t base = blockIdx.x * KP;
+    const int n_here = (m - base) < (uint32_t)KP ? (int)(m - base) : KP;
+    if (threadIdx.x < (unsigned)n_here) sh_pos[threadIdx.x] = positions[base + threadIdx.x];
+    __syncthreads();
+    Acc64<METRIC> A;
+    // the reference calls distance(query, stored) (a = query); every callback is symmetric in
+    // (a, b) bit for bit: x*y and |x-y| commute, (x-y)^2 == (y-x)^2.
+    rescore_rows<METRIC, 256>(master, q64, dim, sh_pos, n_here, tile, qtile, A);
+    if (threadIdx.x < (unsigned)n_here) out[base + threadIdx.x] = hnsw_quantise<METRIC>(A);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ingest: f64 master rows -> f32 slab + 1/|row| cache + domain flags
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ingest(const double* __restrict__ master, float* __restrict__ slab,
+                                                float* __restrict__ inv_norm, uint8_t* __restrict__ flags,
+                                                IngestStats* __restrict__ stats, uint64_t n, uint32_t dim,
+                                                uint32_t ld)
+{
+    const int lane = lane_id();
+    const uint64_t n_waves = (uint64_t)gridDim.x * 4;
+    for (uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += n_waves) {
+        const double* src = master + row * dim;
+        float* dst = slab + row * ld;
+        double ss = 0.0, mx = 0.0;
+        bool bad = false;
+        for (uint32_t c = lane; c < ld; c += WAVE) {
+            const double v = c < dim ? src[c] : 0.0;
+            dst[c] = (float)v;  // round to nearest even
+            ss += v * v;
+            const double av = fabs(v);
+            mx = av > mx ? av : mx;
+            bad |= !(av <= 1.797693134862315708e308);  // inf or NaN
+        }
+#pragma unroll
+        for (int o = WAVE / 2; o >= 1; o >>= 1) {
+            ss += __shfl_xor(ss, o);
+            const double m2 = __shfl_xor(mx, o);
+            mx = m2 > mx ? m2 : mx;
+        }
+        const bool any_bad = __ballot(bad) != 0ull;
+        if (lane == 0) {
+            const double norm = sqrt(ss);
+            const bool ood = any_bad || !(mx <= 1099511627776.0 /* 2^40 */) || !(norm <= 1.0e300) ||
+                             (norm != 0.0 && norm < 9.094947017729282e-13 /* 2^-40 */);
+            inv_norm[row] = (norm > 0.0 && !ood) ? (float)(1.0 / norm) : 0.0f;
+            flags[row] = ood ? ROW_OUT_OF_DOMAIN : 0;
+            if (ood) {
+                atomicAdd(&stats->n_out_of_domain, 1u);
+            } else {
+                atomicMax(&stats->max_norm_bits, (unsigned long long)__double_as_longlong(norm));
+            }
+        }
+    }
+}
+
+template <typename F>
+hipError_t dispatch_metric(int metric, F&& f)
+{
+    switch (metric) {
+    case COSINE: return f(std::integral_constant<int, COSINE>{});
+    case EUCLIDEAN: return f(std::integral_constant<int, EUCLIDEAN>{});
+    case MANHATTAN: return f(std::integral_constant<int, MANHATTAN>{});
+    case DOT: return f(std::integral_constant<int, DOT>{});
+    default: return hipErrorInvalidValue;
+    }
+}
+
+int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_ingest(hipStream_t s, const double* master, float* slab, float* inv_norm, uint8_t* flags,
+                         IngestStats* stats, uint64_t n, uint32_t dim, uint32_t ld)
+{
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + 3) / 4;
+    const int grid = (int)(blocks < 8192 ? blocks : 8192);
+    hipLaunchKernelGGL(k_ingest, dim3(grid), dim3(256), 0, s, master, slab, inv_norm, flags, stats, n, dim, ld);
+    return hipGetLastError();
+}
+
+namespace {
+// lanes per row for a row of ld4 float4
+int lanes_per_row(uint32_t ld4)
+{
+    int g = 1;
+    while (g < 64 && (uint32_t)(g * 2) <= ld4) g *= 2;
+    return g;
+}
+struct ScanShape {
+    bool special;
+    int g, vpl, u;
+};
+ScanShape scan_shape(uint32_t ld4)
+{
+    // specialised instantiations: ld4 = 32 * VPL
+    switch (ld4) {
+    case 32: return {true, 32, 1, 8};
+    case 64: return {true, 32, 2, 4};
+    case 96: return {true, 32, 3, 4};
+    case 128: return {true, 32, 4, 2};
+    case 192: return {true, 32, 6, 2};
+    case 256: return {true, 32, 8, 1};
+    case 384: return {true, 32, 12, 1};
+    default: return {false, lanes_per_row(ld4), 0, 1};
+    }
+}
+}  // namespace
+
+int scan_grid_for(uint64_t n, uint32_t ld)
+{
+    const ScanShape sh = scan_shape(ld / 4);
+    const uint64_t rps = 64 / sh.g;
+    const uint64_t steps = (n + rps - 1) / rps;
+    const uint64_t per_block = 4ull * sh.u;
+    uint64_t blocks = (steps + per_block - 1) / per_block;
+    const uint64_t cap = (uint64_t)env_int("VL_SCAN_GRID", 2048);
+    if (blocks > cap) blocks = cap;
+    if (blocks > (uint64_t)SCAN_MAX_GRID) blocks = SCAN_MAX_GRID;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+hipError_t launch_scan(hipStream_t s, int metric, const float* slab, const float* inv_norm, const float* q32,
+                       uint64_t n, uint32_t ld, Cand32* partials, ScanPlan* plan)
+{
+    if (n == 0 || n >= 0xFFFFFFFFull || (ld & 3)) return hipErrorInvalidValue;
+    const uint32_t ld4 = ld / 4;
+    const ScanShape sh = scan_shape(ld4);
+    const int grid = scan_grid_for(n, ld);
+    if (plan) {
+        plan->grid = grid;
+        plan->variant = sh.special ? sh.vpl : -sh.g;
+    }
+    const f32x4* slab4 = reinterpret_cast<const f32x4*>(slab);
+    const f32x4* q4 = reinterpret_cast<const f32x4*>(q32);
+    const uint32_t n32 = (uint32_t)n;
+    return dispatch_metric(metric, [&](auto M) -> hipError_t {
+        constexpr int MM = decltype(M)::value;
+#define VL_SCAN_CASE(VPL, U)                                                                                  \
+    case VPL:                                                                                                 \
+        hipLaunchKernelGGL((k_scan<MM, 32, VPL, U>), dim3(grid), dim3(256), 0, s, slab4, inv_norm, q4, n32,   \
+                           partials);                                                                         \
+        break;
+        if (sh.special) {
+            switch (sh.vpl) {
+                VL_SCAN_CASE(1, 8)
+                VL_SCAN_CASE(2, 4)
+                VL_SCAN_CASE(3, 4)
+                VL_SCAN_CASE(4, 2)
+                VL_SCAN_CASE(6, 2)
+                VL_SCAN_CASE(8, 1)
+                VL_SCAN_CASE(12, 1)
+            default: return hipErrorInvalidValue;
+            }
+        } else {
+#define VL_SCAN_GEN(G)                                                                                        \
+    case G:                                                                                                   \
+        hipLaunchKernelGGL((k_scan_generic<MM, G>), dim3(grid), dim3(256), 0, s, slab4, inv_norm, q4, n32,    \
+                           ld4, partials);                                                                    \
+        break;
+            switch (sh.g) {
+                VL_SCAN_GEN(1)
+                VL_SCAN_GEN(2)
+                VL_SCAN_GEN(4)
+                VL_SCAN_GEN(8)
+                VL_SCAN_GEN(16)
+                VL_SCAN_GEN(32)
+                VL_SCAN_GEN(64)
+            default: return hipErrorInvalidValue;
+            }
+        }
+#undef VL_SCAN_CASE
+#undef VL_SCAN_GEN
+        return hipGetLastError();
+    });
+}
+
+hipError_t launch_merge_finalize(hipStream_t s, int metric, const Cand32* partials, int n_lists,
+                                 const double* master, const double* q64, uint32_t dim, uint64_t n_rows,
+                                 uint32_t k, double max_row_norm, double q_norm, SearchResultBlock* out)
+{
+    const uint32_t ld = (dim + 3u) & ~3u;
+    return dispatch_metric(metric, [&](auto M) -> hipError_t {
+        constexpr int MM = decltype(M)::value;
+        hipLaunchKernelGGL((k_merge_finalize<MM>), dim3(1), dim3(1024), 0, s, partials, n_lists, master, q64, dim,
+                           ld, n_rows, k, max_row_norm, q_norm, out);
+        return hipGetLastError();
+    });
+}
+
+hipError_t launch_exact_scan(hipStream_t s, int metric, const double* master, const double* q64, uint64_t n,
+                             uint32_t dim, double* scores, uint32_t* nan_flag)
+{
+    if (n == 0) return hipSuccess;
+    const uint64_t tiles = (n + EX_ROWS - 1) / EX_ROWS;
+    const int grid = (int)(tiles < 4096 ? tiles : 4096);
+    return dispatch_metric(metric, [&](auto M) -> hipError_t {
+        constexpr int MM = decltype(M)::value;
+        hipLaunchKernelGGL((k_exact_scan<MM>), dim3(grid), dim3(256), 0, s, master, q64, n, dim, scores, nan_flag);
+        return hipGetLastError();
+    });
+}
+
+int select_grid_for(uint64_t n)
+{
+    const uint64_t steps = (n + 63) / 64;
+    uint64_t blocks = (steps + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+hipError_t launch_exact_select(hipStream_t s, const double* scores, uint64_t n, uint32_t k, Cand64* partials,
+                               const uint32_t* nan_flag, SearchResultBlock* out)
+{
+    if (n == 0 || n >= 0xFFFFFFFFull || k > (uint32_t)KP) return hipErrorInvalidValue;
+    const int grid = select_grid_for(n);
+    hipLaunchKernelGGL(k_select64, dim3(grid), dim3(256), 0, s, scores, (uint32_t)n, partials);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_merge64_emit, dim3(1), dim3(1024), 0, s, partials, grid, n, k, nan_flag, out);
+    return hipGetLastError();
+}
+
+uint64_t sort_capacity_for(uint64_t n)
+{
+    uint64_t cap = SORT_LOCAL;
+    while (cap < n) cap <<= 1;
+    return cap;
+}
+
+hipError_t launch_exact_sort(hipStream_t s, const double* scores, uint64_t n, uint64_t k, uint64_t* okeys,
+                             uint32_t* opos, uint32_t* out_pos, double* out_scores)
+{
+    if (n == 0 || n >= 0xFFFFFFFFull) return hipErrorInvalidValue;
+    const uint64_t cap = sort_capacity_for(n);
+    unsigned long long* ok = reinterpret_cast<unsigned long long*>(okeys);
+    const int tgrid = (int)((cap / 256) < 8192 ? (cap / 256) : 8192);
+    hipLaunchKernelGGL(k_sort_init, dim3(tgrid), dim3(256), 0, s, scores, n, cap, ok, opos);
+    const int lgrid = (int)(cap / SORT_LOCAL);
+    // k = 2 .. SORT_LOCAL entirely in LDS
+    hipLaunchKernelGGL(k_bitonic_local, dim3(lgrid), dim3(1024), 0, s, ok, opos, (uint64_t)2, (uint64_t)SORT_LOCAL);
+    for (uint64_t kk = (uint64_t)SORT_LOCAL << 1; kk <= cap; kk <<= 1) {
+        for (uint64_t j = kk >> 1; j >= (uint64_t)SORT_LOCAL; j >>= 1) {
+            const uint64_t pairs = cap >> 1;
+            const int g = (int)((pairs / 256) < 16384 ? (pairs / 256) : 16384);
+            hipLaunchKernelGGL(k_bitonic_global, dim3(g), dim3(256), 0, s, ok, opos, cap, j, kk);
+        }
+        hipLaunchKernelGGL(k_bitonic_local, dim3(lgrid), dim3(1024), 0, s, ok, opos, kk, kk);
+    }
+    const uint64_t kk = k < n ? k : n;
+    if (kk > 0) {
+        const int egrid = (int)(((kk + 255) / 256) < 4096 ? ((kk + 255) / 256) : 4096);
+        hipLaunchKernelGGL(k_sort_emit, dim3(egrid), dim3(256), 0, s, opos, scores, kk, out_pos, out_scores);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_hnsw_distances(hipStream_t s, int metric, const double* master, const double* q64,
+                                 uint32_t dim, const uint32_t* positions, uint32_t m, uint64_t* out)
+{
+    if (m == 0) return hipSuccess;
+    const int grid = (int)((m + KP - 1) / KP);
+    return dispatch_metric(metric, [&](auto M) -> hipError_t {
+        constexpr int MM = decltype(M)::value;
+        hipLaunchKernelGGL((k_hnsw_dist<MM>), dim3(grid), dim3(256), 0, s, master, q64, dim, positions, m,
+                           reinterpret_cast<unsigned long long*>(out));
+        return hipGetLastError();
+    });
+}
+
+}  // namespace vl

@@ -1,0 +1,91 @@
+// kernels.hpp -- launch interface of the gfx950 kernels (kernels.hip).
+//
+// Every kernel here serves the one hot path this repo implements: the distance
+// scan + top-k of the reference's FlatIndex::search (src/index/flat.rs:98-119,
+// metric math src/lib.rs:425-572) and the HNSW distance callbacks
+// (src/index/hnsw.rs:113-174).  Paths are relative to /root/reference.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace vl {
+
+enum Metric : int { COSINE = 0, EUCLIDEAN = 1, MANHATTAN = 2, DOT = 3 };
+
+constexpr int KP = 64;            // candidate-list length (one entry per lane of a wave)
+constexpr int KFAST_MAX = 32;     // largest k served by the f32 fast path
+constexpr uint32_t POS_SENTINEL = 0xFFFFFFFFu;
+
+struct Cand32 {  // f32 candidate: scan key (larger = better) + storage position
+    float key;
+    uint32_t pos;
+};
+struct Cand64 {  // exact candidate: reference f64 score + storage position
+    double key;
+    uint32_t pos;
+    uint32_t pad;
+};
+
+// Device -> host result block of one search.
+struct SearchResultBlock {
+    uint32_t n_out;
+    uint32_t flags;  // RESULT_* bits
+    uint32_t pos[KP];
+    double score[KP];
+};
+constexpr uint32_t RESULT_NEEDS_EXACT = 1u;  // bound check failed / tie at the cut: redo on the exact path
+constexpr uint32_t RESULT_HAS_NAN = 2u;      // some score is NaN
+
+// Per-index device statistics maintained by the ingest kernel.
+struct IngestStats {
+    unsigned long long max_norm_bits;  // bits of the largest row L2 norm (f64, >= 0)
+    unsigned int n_out_of_domain;      // rows outside the f32 fast-path domain
+    unsigned int pad;
+};
+
+// Row flags produced by ingest.
+constexpr uint8_t ROW_OUT_OF_DOMAIN = 1;
+
+struct ScanPlan {
+    int grid;      // workgroups launched (= partial lists written)
+    int variant;   // which instantiation ran (diagnostics)
+};
+
+// f64 master rows [n, dim] -> f32 slab rows [n, ld] (zero padded), inv_norm[n], flags[n], stats.
+hipError_t launch_ingest(hipStream_t s, const double* master, float* slab, float* inv_norm, uint8_t* flags,
+                         IngestStats* stats, uint64_t n, uint32_t dim, uint32_t ld);
+
+// Number of workgroups launch_scan will use for n rows (partials must hold grid*KP entries).
+int scan_grid_for(uint64_t n, uint32_t ld);
+constexpr int SCAN_MAX_GRID = 4096;
+
+// K1: f32 slab scan -> per-workgroup top-KP partial lists.
+hipError_t launch_scan(hipStream_t s, int metric, const float* slab, const float* inv_norm, const float* q32,
+                       uint64_t n, uint32_t ld, Cand32* partials, ScanPlan* plan);
+
+// K2: merge partial lists -> top-KP, rescore them in reference f64 arithmetic from the master
+// rows, rank by (score desc, pos asc), run the exactness bound check, write the result block.
+hipError_t launch_merge_finalize(hipStream_t s, int metric, const Cand32* partials, int n_lists,
+                                 const double* master, const double* q64, uint32_t dim, uint64_t n_rows,
+                                 uint32_t k, double max_row_norm, double q_norm, SearchResultBlock* out);
+
+// Exact path: reference-order f64 score of every row.
+hipError_t launch_exact_scan(hipStream_t s, int metric, const double* master, const double* q64, uint64_t n,
+                             uint32_t dim, double* scores, uint32_t* nan_flag);
+// Exact path, k <= KP: top-k of scores[] by (score desc, pos asc).
+int select_grid_for(uint64_t n);
+hipError_t launch_exact_select(hipStream_t s, const double* scores, uint64_t n, uint32_t k, Cand64* partials,
+                               const uint32_t* nan_flag, SearchResultBlock* out);
+// Exact path, any k: device-wide sort of (score desc, pos asc); writes the first k.
+// okeys/opos are scratch of next_pow2(n) entries.
+uint64_t sort_capacity_for(uint64_t n);
+hipError_t launch_exact_sort(hipStream_t s, const double* scores, uint64_t n, uint64_t k, uint64_t* okeys,
+                             uint32_t* opos, uint32_t* out_pos, double* out_scores);
+
+// HNSW distance callbacks: u64 distance of query vs the rows at positions[0..m).
+hipError_t launch_hnsw_distances(hipStream_t s, int metric, const double* master, const double* q64,
+                                 uint32_t dim, const uint32_t* positions, uint32_t m, uint64_t* out);
+
+}  // namespace vl
