@@ -1,0 +1,54 @@
+"""Static checks on the gfx950 ISA hipcc emits for kernels.hip (CPU only, cross-compile)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    from vectorlite_amd import build as vbuild
+    out = tmp_path_factory.mktemp("isa") / "kernels.s"
+    cmd = [vbuild.hipcc(), f"--offload-arch={vbuild.ARCH}"] + vbuild.COMMON + [
+        "--cuda-device-only", "-S", os.path.join(vbuild.CSRC, "kernels.hip"), "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return out.read_text()
+
+
+def test_no_unencodable_64bit_scalar_literal(device_asm):
+    # ROCm 7.2 hipcc can emit `s_mov_b64 s[a:b], <64-bit literal>` for gfx950, which the hardware
+    # encoding truncates to 32 bits (found on MI355X: a -inf f64 threshold became +0.0).
+    bad = re.findall(r"s_mov_b64 s\[\d+:\d+\], 0x[0-9a-f]{9,}", device_asm)
+    assert bad == []
+
+
+def _kernel_body(asm, mangled_fragment):
+    m = re.search(r"^(_Z\S*%s\S*):[^\n]*\n(.*?)s_endpgm" % re.escape(mangled_fragment), asm, flags=re.S | re.M)
+    assert m, mangled_fragment
+    return m.group(2)
+
+
+def test_exact_kernels_do_not_contract_multiply_add(device_asm):
+    # the reference's f64 loops are separate multiply and add (src/lib.rs:430-434, 479-482, 568-571):
+    # the accumulation loops must use v_mul_f64 / v_add_f64; v_fma_f64 may only appear in the
+    # correctly rounded sqrt/division expansions after the loop.
+    for frag in ("12k_exact_scanILi0E", "12k_exact_scanILi1E", "12k_exact_scanILi3E"):
+        body = _kernel_body(device_asm, frag)
+        assert "v_mul_f64" in body and "v_add_f64" in body
+        last_mul = body.rfind("v_mul_f64")
+        first_fma = body.find("v_fma_f64")
+        assert first_fma == -1 or "v_rsq_f64" in body[:first_fma] or "v_rcp_f64" in body[:first_fma], frag
+        assert last_mul != -1
+
+
+def test_scan_kernel_streams_with_16_byte_nontemporal_loads(device_asm):
+    body = _kernel_body(device_asm, "6k_scanILi0ELi8ELi12ELi1E")  # default shape for dim = 384
+    nt = re.findall(r"global_load_dwordx4 .* nt", body)
+    assert len(nt) == 12  # 12 float4 per lane (one row group of 8 rows) in flight
+    assert "scratch_" not in body and "buffer_store" not in body  # no spills
+    meta = re.search(r"\.name:\s+_ZN2vl12_GLOBAL__N_16k_scanILi0ELi8ELi12ELi1E.*?\.vgpr_count:\s+(\d+)", device_asm, re.S)
+    if meta:
+        assert int(meta.group(1)) <= 128

@@ -78,11 +78,11 @@ Workspace::~Workspace()
 {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
-    void* dev[] = {d_q32, d_q64, d_partials, d_partials64, d_result, d_nan, d_scores, d_okeys,
+    void* dev[] = {d_q64, d_partials, d_partials64, d_result, d_nan, d_scores, d_okeys,
                    d_opos, d_out_pos, d_out_scores, d_positions, d_dists};
     for (void* p : dev)
         if (p) (void)hipFree(p);
-    void* host[] = {h_q32, h_q64, h_result, h_nan};
+    void* host[] = {h_q64, h_result, h_nan};
     for (void* p : host)
         if (p) (void)hipHostFree(p);
     if (ev0) (void)hipEventDestroy(ev0);
@@ -351,12 +351,10 @@ int GpuFlatIndex::prepare_ws(Workspace* ws) const
     VL_HIP(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
     const size_t qn = std::max<size_t>(ld_, 4);
     ws->q_cap = qn;
-    VL_TRY(dev_alloc(&ws->d_q32, qn));
     VL_TRY(dev_alloc(&ws->d_q64, qn));
-    VL_TRY(pinned_alloc(&ws->h_q32, qn));
     VL_TRY(pinned_alloc(&ws->h_q64, qn));
-    VL_TRY(dev_alloc(&ws->d_partials, (size_t)SCAN_MAX_GRID * KP));
-    VL_TRY(dev_alloc(&ws->d_partials64, (size_t)1024 * KP));
+    VL_TRY(dev_alloc(&ws->d_partials, PARTIALS32_ENTRIES));
+    VL_TRY(dev_alloc(&ws->d_partials64, PARTIALS64_ENTRIES));
     VL_TRY(dev_alloc(&ws->d_result, 1));
     VL_TRY(pinned_alloc(&ws->h_result, 1));
     VL_TRY(dev_alloc(&ws->d_nan, 1));
@@ -447,19 +445,15 @@ int GpuFlatIndex::search_locked(Workspace* ws, const double* query, uint64_t k_e
     for (uint64_t i = 0; i < dim_; ++i) {
         const double v = query[i];
         ws->h_q64[i] = v;
-        ws->h_q32[i] = (float)v;
         qq += v * v;
         const double av = std::fabs(v);
         if (!(av <= 1.797693134862315708e308)) q_finite = false;
         if (av > qmax) qmax = av;
     }
-    for (uint64_t i = dim_; i < ld_; ++i) ws->h_q32[i] = 0.0f;
     const double q_norm = std::sqrt(qq);
     const bool q_in_domain = q_finite && qmax <= DOMAIN_MAX_ABS && (q_norm == 0.0 || q_norm >= DOMAIN_MIN_NORM);
-    if (dim_) {
-        VL_HIP(hipMemcpyAsync(ws->d_q64, ws->h_q64, dim_ * sizeof(double), hipMemcpyHostToDevice, st));
-        VL_HIP(hipMemcpyAsync(ws->d_q32, ws->h_q32, ld_ * sizeof(float), hipMemcpyHostToDevice, st));
-    }
+    // one small H2D copy per query; the scan kernel rounds its f32 copy of the query itself
+    VL_HIP(hipMemcpyAsync(ws->d_q64, ws->h_q64, dim_ * sizeof(double), hipMemcpyHostToDevice, st));
 
     const int forced = force_path_.load();
     const bool fast_ok = forced == 0 && dim_ > 0 && k_eff <= (uint64_t)KFAST_MAX && n_out_of_domain_ == 0 &&
@@ -468,11 +462,11 @@ int GpuFlatIndex::search_locked(Workspace* ws, const double* query, uint64_t k_e
         const bool prof = profile_.load();
         ScanPlan plan;
         if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
-        VL_HIP(launch_scan(st, metric, d_slab_, d_inv_norm_, ws->d_q32, n, ld_, ws->d_partials, &plan));
+        VL_HIP(launch_scan(st, metric, d_slab_, d_inv_norm_, ws->d_q64, n, (uint32_t)dim_, ld_, ws->d_partials, &plan));
         if (prof) VL_HIP(hipEventRecord(ws->ev1, st));
+        // the finalize kernel stores the 1 KB result block straight into pinned host memory
         VL_HIP(launch_merge_finalize(st, metric, ws->d_partials, plan.grid, d_master_, ws->d_q64, (uint32_t)dim_,
-                                     n, (uint32_t)k_eff, max_row_norm_, q_norm, ws->d_result));
-        VL_HIP(hipMemcpyAsync(ws->h_result, ws->d_result, sizeof(SearchResultBlock), hipMemcpyDeviceToHost, st));
+                                     n, (uint32_t)k_eff, max_row_norm_, q_norm, ws->h_result));
         VL_HIP(hipStreamSynchronize(st));
         if (prof) {
             float ms = 0.f;
@@ -486,6 +480,10 @@ int GpuFlatIndex::search_locked(Workspace* ws, const double* query, uint64_t k_e
         if (!(r.flags & RESULT_NEEDS_EXACT) && r.n_out == k_eff) {
             for (uint64_t i = 0; i < k_eff; ++i) {
                 const uint32_t p = r.pos[i];
+                if (p >= n) {
+                    set_last_error("fast path returned an out-of-range position (kernel bug)");
+                    return ERR_DEVICE;
+                }
                 if (out_pos) out_pos[i] = p;
                 if (out_ids) out_ids[i] = ids_[p];
                 out_scores[i] = r.score[i];
@@ -501,6 +499,10 @@ int GpuFlatIndex::search_locked(Workspace* ws, const double* query, uint64_t k_e
     std::vector<double> scores;
     VL_TRY(run_exact(ws, metric, n, k_eff, &pos, &scores));
     for (uint64_t i = 0; i < k_eff; ++i) {
+        if (pos[i] >= n) {
+            set_last_error("exact path returned an out-of-range position (kernel bug)");
+            return ERR_DEVICE;
+        }
         if (out_pos) out_pos[i] = pos[i];
         if (out_ids) out_ids[i] = ids_[pos[i]];
         out_scores[i] = scores[i];

@@ -48,9 +48,7 @@ int last_path();
 struct Workspace {
     int device = 0;
     hipStream_t stream = nullptr;
-    float* d_q32 = nullptr;
     double* d_q64 = nullptr;
-    float* h_q32 = nullptr;   // pinned
     double* h_q64 = nullptr;  // pinned
     size_t q_cap = 0;
     Cand32* d_partials = nullptr;

@@ -25,6 +25,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 namespace vl {
@@ -42,6 +43,27 @@ template <typename K>
 __device__ __forceinline__ bool better(K ka, uint32_t pa, K kb, uint32_t pb)
 {
     return ka > kb || (ka == kb && pa < pb);
+}
+
+// ---- cross-lane moves without LDS traffic ------------------------------------------------------
+// lane i <- lane i-1 (lane 0 keeps its own value): one DPP wave_shr:1 move per dword.
+__device__ __forceinline__ int wave_shr1_dw(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xF, 0xF, false); }
+__device__ __forceinline__ float wave_shr1(float v) { return __int_as_float(wave_shr1_dw(__float_as_int(v))); }
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return (uint32_t)wave_shr1_dw((int)v); }
+__device__ __forceinline__ double wave_shr1(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = wave_shr1_dw((int)(b & 0xFFFFFFFFll)), hi = wave_shr1_dw((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// value of a wave-uniform lane (v_readlane_b32 into an SGPR)
+__device__ __forceinline__ float read_lane(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ uint32_t read_lane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ __forceinline__ double read_lane(double v, int lane)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
 template <typename K>
@@ -65,7 +87,11 @@ struct TopList {
     {
         key = neg_inf<K>();
         pos = POS_SENTINEL;
-        thr_key = neg_inf<K>();
+        // Keep the f64 -inf out of constant propagation: hipcc (ROCm 7.2) otherwise materialises the
+        // wave-uniform threshold with `s_mov_b64 s[..], 0xfff0000000000000`, a 64-bit literal gfx950
+        // cannot encode (it is truncated to 32 bits: the threshold silently becomes +0.0).
+        asm volatile("" : "+v"(key));
+        thr_key = read_lane(key, WAVE - 1);
         thr_pos = POS_SENTINEL;
     }
 
@@ -74,8 +100,8 @@ struct TopList {
         // entries that stay in front of (k, p): a prefix of the lanes because the list is sorted
         const unsigned long long ahead = __ballot(better<K>(key, pos, k, p));
         const int idx = __popcll(ahead);
-        const K upk = __shfl_up(key, 1);
-        const uint32_t upp = __shfl_up(pos, 1);
+        const K upk = wave_shr1(key);
+        const uint32_t upp = wave_shr1(pos);
         const int lane = lane_id();
         if (lane == idx) {
             key = k;
@@ -84,8 +110,8 @@ struct TopList {
             key = upk;
             pos = upp;
         }
-        thr_key = __shfl(key, WAVE - 1);
-        thr_pos = __shfl(pos, WAVE - 1);
+        thr_key = read_lane(key, WAVE - 1);
+        thr_pos = read_lane(pos, WAVE - 1);
     }
 
     // Every lane may offer one (key, pos); lanes are drained in lane order.
@@ -93,9 +119,9 @@ struct TopList {
     {
         unsigned long long m = __ballot(active && better<K>(k, p, thr_key, thr_pos));
         while (m) {
-            const int src = __ffsll((long long)m) - 1;
+            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
             m &= m - 1;
-            insert(__shfl(k, src), __shfl(p, src));
+            insert(read_lane(k, src), read_lane(p, src));
         }
     }
 
@@ -119,8 +145,8 @@ struct TopList {
                 pos = p2;
             }
         }
-        thr_key = __shfl(key, WAVE - 1);
-        thr_pos = __shfl(pos, WAVE - 1);
+        thr_key = read_lane(key, WAVE - 1);
+        thr_pos = read_lane(pos, WAVE - 1);
     }
 };
 
@@ -142,6 +168,53 @@ __device__ __forceinline__ void block_merge(TopList<K>& L, C* sh /* [NW][64] */)
             sh[wave * WAVE + lane].pos = L.pos;
         }
         __syncthreads();
+    }
+}
+
+// Fold up to 4 consecutive sorted lists (global memory) into L with bitonic merges.
+template <typename K, typename C>
+__device__ __forceinline__ void fold_lists4(TopList<K>& L, const C* __restrict__ lists, int first, int count)
+{
+    const int lane = lane_id();
+    L.init();
+    C e[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // all loads in flight together
+        const int li = first + (i < count ? i : 0);
+        const int slot = i == 0 ? lane : (KP - 1 - lane);
+        if (count > 0) e[i] = lists[(size_t)li * KP + slot];
+    }
+    if (count > 0) {
+        L.key = e[0].key;
+        L.pos = e[0].pos;
+    }
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < count) L.merge_reversed(e[i].key, e[i].pos);
+    L.thr_key = read_lane(L.key, WAVE - 1);
+    L.thr_pos = read_lane(L.pos, WAVE - 1);
+}
+
+// Merge level: workgroup b folds lists [64b, 64b+64) (16 waves x 4 lists, then a 4-level tree)
+// into one sorted list out[b].
+template <typename K, typename C>
+__global__ __launch_bounds__(1024) void k_merge_lists(const C* __restrict__ lists, int n_lists, C* __restrict__ out)
+{
+    constexpr int NW = 16;
+    __shared__ C sh[NW * WAVE];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int first = blockIdx.x * 64 + wave * 4;
+    int count = n_lists - first;
+    count = count < 0 ? 0 : (count > 4 ? 4 : count);
+    TopList<K> L;
+    fold_lists4<K, C>(L, lists, first, count);
+    block_merge<K, C, NW>(L, sh);
+    if (wave == 0) {
+        C e = {};
+        e.key = L.key;
+        e.pos = L.pos;
+        out[(size_t)blockIdx.x * KP + lane] = e;
     }
 }
 
@@ -182,6 +255,20 @@ __device__ __forceinline__ float scan_key(float sum, float inv_norm)
     return -sum;
 }
 
+// The query arrives as f64 (the reference's `search(&[f64])`); each lane rounds its own slice to
+// f32 (round to nearest even, the same rounding the slab rows got at ingest).  Columns past `dim`
+// (slab padding) read as zero.
+__device__ __forceinline__ f32x4 load_q4(const double* __restrict__ q64, uint32_t j4, uint32_t dim)
+{
+    const uint32_t i = j4 * 4;
+    f32x4 r;
+    r.x = i + 0 < dim ? (float)q64[i + 0] : 0.0f;
+    r.y = i + 1 < dim ? (float)q64[i + 1] : 0.0f;
+    r.z = i + 2 < dim ? (float)q64[i + 2] : 0.0f;
+    r.w = i + 3 < dim ? (float)q64[i + 3] : 0.0f;
+    return r;
+}
+
 template <int G>
 __device__ __forceinline__ float group_reduce(float a)
 {
@@ -193,7 +280,8 @@ __device__ __forceinline__ float group_reduce(float a)
 // Specialised: ld4 == G * VPL float4 per row, U row groups in flight per wave.
 template <int METRIC, int G, int VPL, int U>
 __global__ __launch_bounds__(256) void k_scan(const f32x4* __restrict__ slab, const float* __restrict__ inv_norm,
-                                              const f32x4* __restrict__ q, uint32_t n, Cand32* __restrict__ out)
+                                              const double* __restrict__ q64, uint32_t dim, uint32_t n,
+                                              Cand32* __restrict__ out)
 {
     constexpr int RPS = WAVE / G;  // rows per step of one wave
     constexpr uint32_t LD4 = G * VPL;
@@ -205,7 +293,7 @@ __global__ __launch_bounds__(256) void k_scan(const f32x4* __restrict__ slab, co
 
     f32x4 qv[VPL];
 #pragma unroll
-    for (int j = 0; j < VPL; ++j) qv[j] = q[c + G * j];
+    for (int j = 0; j < VPL; ++j) qv[j] = load_q4(q64, c + G * j, dim);
 
     const uint32_t n_steps = (n + RPS - 1) / RPS;
     const uint32_t n_waves = gridDim.x * 4;
@@ -253,8 +341,8 @@ __global__ __launch_bounds__(256) void k_scan(const f32x4* __restrict__ slab, co
 template <int METRIC, int G>
 __global__ __launch_bounds__(256) void k_scan_generic(const f32x4* __restrict__ slab,
                                                       const float* __restrict__ inv_norm,
-                                                      const f32x4* __restrict__ q, uint32_t n, uint32_t ld4,
-                                                      Cand32* __restrict__ out)
+                                                      const double* __restrict__ q64, uint32_t dim, uint32_t n,
+                                                      uint32_t ld4, Cand32* __restrict__ out)
 {
     constexpr int RPS = WAVE / G;
     __shared__ Cand32 sh[4 * WAVE];
@@ -275,7 +363,7 @@ __global__ __launch_bounds__(256) void k_scan_generic(const f32x4* __restrict__ 
         const uint32_t r = valid ? row : n - 1;
         const f32x4* p = slab + (size_t)r * ld4;
         float a = 0.0f;
-        for (uint32_t j = c; j < ld4; j += G) a = acc4<METRIC>(a, p[j], q[j]);
+        for (uint32_t j = c; j < ld4; j += G) a = acc4<METRIC>(a, p[j], load_q4(q64, j, dim));
         a = group_reduce<G>(a);
         float inv = 1.0f;
         if (METRIC == COSINE) inv = inv_norm[r];
@@ -383,7 +471,18 @@ __device__ __forceinline__ void rescore_rows(const double* __restrict__ master, 
         if (tid < RESCORE_CH && (uint32_t)tid < cw) qtile[tid] = q64[c0 + tid];
         __syncthreads();
         if (tid < n_rows) {
-            for (uint32_t cc = 0; cc < cw; ++cc) A.step(tile[tid][cc], qtile[cc]);
+            uint32_t cc = 0;
+            for (; cc + 8 <= cw; cc += 8) {  // 16 LDS reads in flight, then 8 steps in index order
+                double xv[8], yv[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    xv[t] = tile[tid][cc + t];
+                    yv[t] = qtile[cc + t];
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) A.step(xv[t], yv[t]);
+            }
+            for (; cc < cw; ++cc) A.step(tile[tid][cc], qtile[cc]);
         }
     }
 }
@@ -435,12 +534,13 @@ __global__ __launch_bounds__(1024) void k_merge_finalize(const Cand32* __restric
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
 
-    // phase 1: 16 waves fold the partial lists, then a 4-level bitonic tree merge
+    // phase 1: n_lists <= 64 sorted lists: 16 waves x 4 bitonic folds, then a 4-level tree merge
     TopList<float> L;
-    L.init();
-    for (int l = wave; l < n_lists; l += NW) {
-        const Cand32 e = partials[(size_t)l * KP + lane];
-        L.offer(e.key, e.pos, e.pos != POS_SENTINEL);
+    {
+        const int first = wave * 4;
+        int count = n_lists - first;
+        count = count < 0 ? 0 : (count > 4 ? 4 : count);
+        fold_lists4<float, Cand32>(L, partials, first, count);
     }
     block_merge<float, Cand32, NW>(L, sh_lists);
     if (wave == 0) {
@@ -578,10 +678,11 @@ __global__ __launch_bounds__(1024) void k_merge64_emit(const Cand64* __restrict_
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     TopList<double> L;
-    L.init();
-    for (int l = wave; l < n_lists; l += NW) {
-        const Cand64 e = partials[(size_t)l * KP + lane];
-        L.offer(e.key, e.pos, e.pos != POS_SENTINEL);
+    {
+        const int first = wave * 4;
+        int count = n_lists - first;
+        count = count < 0 ? 0 : (count > 4 ? 4 : count);
+        fold_lists4<double, Cand64>(L, partials, first, count);
     }
     block_merge<double, Cand64, NW>(L, sh);
     if (wave == 0) {
@@ -800,85 +901,143 @@ hipError_t launch_ingest(hipStream_t s, const double* master, float* slab, float
 }
 
 namespace {
-// lanes per row for a row of ld4 float4
+// lanes per row for a row of ld4 float4 (generic kernel)
 int lanes_per_row(uint32_t ld4)
 {
     int g = 1;
     while (g < 64 && (uint32_t)(g * 2) <= ld4) g *= 2;
     return g;
 }
+
+// Compiled (G lanes per row, VPL float4 per lane, U row groups in flight, BPC workgroups per CU)
+// instantiations of k_scan.  The first entry whose G*VPL equals ld4 is the default; VL_SCAN_G /
+// VL_SCAN_U / VL_SCAN_GRID pick another shape (tuning only).  Measured on MI355X at N=10M, dim=384
+// (profiles/r01_tune_scan.txt): 12 x 16-byte loads in flight per lane and 3 workgroups per CU
+// (12 waves, ~144 KB in flight per CU) stream at 7.17 TB/s; more resident waves were slower.
+#define VL_SCAN_VARIANTS(X)                                                                         \
+    X(8, 4, 3, 3) X(8, 8, 2, 3) X(8, 12, 1, 3) X(8, 16, 1, 3) X(16, 12, 1, 3) X(16, 16, 1, 3)       \
+    X(16, 24, 1, 2) X(32, 1, 8, 4) X(32, 2, 4, 4) X(32, 4, 2, 4) X(32, 8, 1, 4) X(32, 12, 1, 3)      \
+    X(32, 3, 2, 4) X(32, 3, 4, 3) X(16, 6, 1, 4) X(16, 6, 2, 1) X(8, 12, 2, 1) X(4, 24, 1, 2)        \
+    X(32, 6, 1, 4) X(32, 6, 2, 3) X(16, 12, 2, 1) X(8, 24, 1, 2) X(64, 3, 2, 4) X(64, 3, 4, 3)       \
+    X(16, 2, 4, 4) X(8, 4, 4, 3) X(16, 4, 2, 4) X(16, 4, 3, 3) X(8, 8, 1, 4) X(16, 8, 1, 4)          \
+    X(16, 8, 2, 2)
+
 struct ScanShape {
     bool special;
-    int g, vpl, u;
+    int g, vpl, u, bpc;
 };
+
 ScanShape scan_shape(uint32_t ld4)
 {
-    // specialised instantiations: ld4 = 32 * VPL
-    switch (ld4) {
-    case 32: return {true, 32, 1, 8};
-    case 64: return {true, 32, 2, 4};
-    case 96: return {true, 32, 3, 4};
-    case 128: return {true, 32, 4, 2};
-    case 192: return {true, 32, 6, 2};
-    case 256: return {true, 32, 8, 1};
-    case 384: return {true, 32, 12, 1};
-    default: return {false, lanes_per_row(ld4), 0, 1};
+    static const int table[][4] = {
+#define VL_ROW(G, VPL, U, BPC) {G, VPL, U, BPC},
+        VL_SCAN_VARIANTS(VL_ROW)
+#undef VL_ROW
+    };
+    const int want_g = env_int("VL_SCAN_G", 0), want_u = env_int("VL_SCAN_U", 0);
+    const int n = (int)(sizeof(table) / sizeof(table[0]));
+    int pick = -1;
+    for (int i = 0; i < n; ++i) {
+        if ((uint32_t)(table[i][0] * table[i][1]) != ld4) continue;
+        if (pick < 0) pick = i;
+        if (want_g && table[i][0] == want_g && (!want_u || table[i][2] == want_u)) {
+            pick = i;
+            break;
+        }
+        if (!want_g && want_u && table[i][2] == want_u && table[i][0] == table[pick][0]) {
+            pick = i;
+            break;
+        }
     }
+    if (pick < 0) return {false, lanes_per_row(ld4), 0, 1, 4};
+    return {true, table[pick][0], table[pick][1], table[pick][2], table[pick][3]};
 }
 }  // namespace
 
-int scan_grid_for(uint64_t n, uint32_t ld)
+namespace {
+// Workgroups of `kernel` (256 threads, no dynamic LDS) that are resident at once on this device:
+// the scan is one persistent wave of workgroups that grid-stride over the rows, so every CU streams
+// for the whole launch and no second, partially filled round of workgroups trails behind.
+int resident_blocks(const void* kernel, int* n_cus)
 {
-    const ScanShape sh = scan_shape(ld / 4);
+    struct Entry {
+        const void* k;
+        int dev;
+        int blocks;
+        int cus;
+    };
+    static Entry cache[256];
+    static int n_cache = 0;
+    static std::mutex mu;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    for (int i = 0; i < n_cache; ++i)
+        if (cache[i].k == kernel && cache[i].dev == dev) {
+            *n_cus = cache[i].cus;
+            return cache[i].blocks;
+        }
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    // the occupancy API can over-report by one block per CU (MI355X_MICROARCH.md): stay one below 8
+    if (per_cu > 7) per_cu = 7;
+    const int blocks = per_cu * cus;
+    if (n_cache < 256) cache[n_cache++] = {kernel, dev, blocks, cus};
+    *n_cus = cus;
+    return blocks;
+}
+
+int scan_grid(uint64_t n, const ScanShape& sh, const void* kernel)
+{
     const uint64_t rps = 64 / sh.g;
     const uint64_t steps = (n + rps - 1) / rps;
     const uint64_t per_block = 4ull * sh.u;
     uint64_t blocks = (steps + per_block - 1) / per_block;
-    const uint64_t cap = (uint64_t)env_int("VL_SCAN_GRID", 2048);
+    uint64_t cap = (uint64_t)env_int("VL_SCAN_GRID", 0);
+    if (cap == 0) {
+        int cus = 0;
+        const uint64_t resident = (uint64_t)resident_blocks(kernel, &cus);
+        cap = (uint64_t)sh.bpc * (uint64_t)cus;
+        if (cap > resident) cap = resident;
+    }
     if (blocks > cap) blocks = cap;
     if (blocks > (uint64_t)SCAN_MAX_GRID) blocks = SCAN_MAX_GRID;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
+}  // namespace
 
-hipError_t launch_scan(hipStream_t s, int metric, const float* slab, const float* inv_norm, const float* q32,
-                       uint64_t n, uint32_t ld, Cand32* partials, ScanPlan* plan)
+hipError_t launch_scan(hipStream_t s, int metric, const float* slab, const float* inv_norm, const double* q64,
+                       uint64_t n, uint32_t dim, uint32_t ld, Cand32* partials, ScanPlan* plan)
 {
     if (n == 0 || n >= 0xFFFFFFFFull || (ld & 3)) return hipErrorInvalidValue;
     const uint32_t ld4 = ld / 4;
     const ScanShape sh = scan_shape(ld4);
-    const int grid = scan_grid_for(n, ld);
-    if (plan) {
-        plan->grid = grid;
-        plan->variant = sh.special ? sh.vpl : -sh.g;
-    }
     const f32x4* slab4 = reinterpret_cast<const f32x4*>(slab);
-    const f32x4* q4 = reinterpret_cast<const f32x4*>(q32);
     const uint32_t n32 = (uint32_t)n;
-    return dispatch_metric(metric, [&](auto M) -> hipError_t {
+    int grid = 0;
+    hipError_t rc = dispatch_metric(metric, [&](auto M) -> hipError_t {
         constexpr int MM = decltype(M)::value;
-#define VL_SCAN_CASE(VPL, U)                                                                                  \
-    case VPL:                                                                                                 \
-        hipLaunchKernelGGL((k_scan<MM, 32, VPL, U>), dim3(grid), dim3(256), 0, s, slab4, inv_norm, q4, n32,   \
-                           partials);                                                                         \
-        break;
         if (sh.special) {
-            switch (sh.vpl) {
-                VL_SCAN_CASE(1, 8)
-                VL_SCAN_CASE(2, 4)
-                VL_SCAN_CASE(3, 4)
-                VL_SCAN_CASE(4, 2)
-                VL_SCAN_CASE(6, 2)
-                VL_SCAN_CASE(8, 1)
-                VL_SCAN_CASE(12, 1)
-            default: return hipErrorInvalidValue;
-            }
+            bool launched = false;
+#define VL_TRY_VARIANT(G, VPL, U, BPC)                                                                          \
+    if (!launched && sh.g == G && sh.vpl == VPL && sh.u == U) {                                             \
+        auto kern = k_scan<MM, G, VPL, U>;                                                                   \
+        grid = scan_grid(n, sh, reinterpret_cast<const void*>(kern));                                        \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, slab4, inv_norm, q64, dim, n32, partials);           \
+        launched = true;                                                                                     \
+    }
+            VL_SCAN_VARIANTS(VL_TRY_VARIANT)
+#undef VL_TRY_VARIANT
+            if (!launched) return hipErrorInvalidValue;
         } else {
 #define VL_SCAN_GEN(G)                                                                                        \
-    case G:                                                                                                   \
-        hipLaunchKernelGGL((k_scan_generic<MM, G>), dim3(grid), dim3(256), 0, s, slab4, inv_norm, q4, n32,    \
-                           ld4, partials);                                                                    \
-        break;
+    case G: {                                                                                                 \
+        auto kern = k_scan_generic<MM, G>;                                                                    \
+        grid = scan_grid(n, sh, reinterpret_cast<const void*>(kern));                                         \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, slab4, inv_norm, q64, dim, n32, ld4, partials);       \
+    } break;
             switch (sh.g) {
                 VL_SCAN_GEN(1)
                 VL_SCAN_GEN(2)
@@ -889,18 +1048,45 @@ hipError_t launch_scan(hipStream_t s, int metric, const float* slab, const float
                 VL_SCAN_GEN(64)
             default: return hipErrorInvalidValue;
             }
-        }
-#undef VL_SCAN_CASE
 #undef VL_SCAN_GEN
+        }
         return hipGetLastError();
     });
+    if (plan) {
+        plan->grid = grid;
+        plan->variant = sh.special ? (sh.g * 10000 + sh.vpl * 100 + sh.u) : -sh.g;
+    }
+    return rc;
 }
 
-hipError_t launch_merge_finalize(hipStream_t s, int metric, const Cand32* partials, int n_lists,
+namespace {
+// Reduce n_lists sorted lists to <= 64 with merge levels; `scratch` holds two ping-pong regions of
+// 64 lists each.  Returns the final list array and count.
+template <typename K, typename C>
+const C* reduce_lists(hipStream_t s, const C* lists, int* n_lists, C* scratch)
+{
+    int n = *n_lists;
+    int ping = 0;
+    while (n > 64) {
+        const int blocks = (n + 63) / 64;
+        C* out = scratch + (size_t)ping * 64 * KP;
+        hipLaunchKernelGGL((k_merge_lists<K, C>), dim3(blocks), dim3(1024), 0, s, lists, n, out);
+        lists = out;
+        n = blocks;
+        ping ^= 1;
+    }
+    *n_lists = n;
+    return lists;
+}
+}  // namespace
+
+hipError_t launch_merge_finalize(hipStream_t s, int metric, Cand32* partials, int n_lists,
                                  const double* master, const double* q64, uint32_t dim, uint64_t n_rows,
                                  uint32_t k, double max_row_norm, double q_norm, SearchResultBlock* out)
 {
     const uint32_t ld = (dim + 3u) & ~3u;
+    const Cand32* lists = reduce_lists<float, Cand32>(s, partials, &n_lists, partials + (size_t)SCAN_MAX_GRID * KP);
+    partials = const_cast<Cand32*>(lists);
     return dispatch_metric(metric, [&](auto M) -> hipError_t {
         constexpr int MM = decltype(M)::value;
         hipLaunchKernelGGL((k_merge_finalize<MM>), dim3(1), dim3(1024), 0, s, partials, n_lists, master, q64, dim,
@@ -926,7 +1112,7 @@ int select_grid_for(uint64_t n)
 {
     const uint64_t steps = (n + 63) / 64;
     uint64_t blocks = (steps + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > (uint64_t)SELECT_MAX_GRID) blocks = SELECT_MAX_GRID;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
@@ -939,7 +1125,9 @@ hipError_t launch_exact_select(hipStream_t s, const double* scores, uint64_t n, 
     hipLaunchKernelGGL(k_select64, dim3(grid), dim3(256), 0, s, scores, (uint32_t)n, partials);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_merge64_emit, dim3(1), dim3(1024), 0, s, partials, grid, n, k, nan_flag, out);
+    int n_lists = grid;
+    const Cand64* lists = reduce_lists<double, Cand64>(s, partials, &n_lists, partials + (size_t)SELECT_MAX_GRID * KP);
+    hipLaunchKernelGGL(k_merge64_emit, dim3(1), dim3(1024), 0, s, lists, n_lists, n, k, nan_flag, out);
     return hipGetLastError();
 }
 

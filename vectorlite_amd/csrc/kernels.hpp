@@ -57,17 +57,21 @@ struct ScanPlan {
 hipError_t launch_ingest(hipStream_t s, const double* master, float* slab, float* inv_norm, uint8_t* flags,
                          IngestStats* stats, uint64_t n, uint32_t dim, uint32_t ld);
 
-// Number of workgroups launch_scan will use for n rows (partials must hold grid*KP entries).
-int scan_grid_for(uint64_t n, uint32_t ld);
+// Upper bound on the workgroups launch_scan uses (partials must hold SCAN_MAX_GRID*KP entries).
 constexpr int SCAN_MAX_GRID = 4096;
+constexpr int SELECT_MAX_GRID = 1024;
+// partial-list buffers hold the scan/select lists plus two 64-list merge regions
+constexpr size_t PARTIALS32_ENTRIES = (size_t)(SCAN_MAX_GRID + 128) * KP;
+constexpr size_t PARTIALS64_ENTRIES = (size_t)(SELECT_MAX_GRID + 128) * KP;
 
 // K1: f32 slab scan -> per-workgroup top-KP partial lists.
-hipError_t launch_scan(hipStream_t s, int metric, const float* slab, const float* inv_norm, const float* q32,
-                       uint64_t n, uint32_t ld, Cand32* partials, ScanPlan* plan);
+hipError_t launch_scan(hipStream_t s, int metric, const float* slab, const float* inv_norm, const double* q64,
+                       uint64_t n, uint32_t dim, uint32_t ld, Cand32* partials, ScanPlan* plan);
 
+// `out` may be pinned host memory (the result block is written once, by one wave).
 // K2: merge partial lists -> top-KP, rescore them in reference f64 arithmetic from the master
 // rows, rank by (score desc, pos asc), run the exactness bound check, write the result block.
-hipError_t launch_merge_finalize(hipStream_t s, int metric, const Cand32* partials, int n_lists,
+hipError_t launch_merge_finalize(hipStream_t s, int metric, Cand32* partials, int n_lists,
                                  const double* master, const double* q64, uint32_t dim, uint64_t n_rows,
                                  uint32_t k, double max_row_norm, double q_norm, SearchResultBlock* out);
 
