@@ -130,6 +130,11 @@ int vl_index_export(const vl_index *h, uint64_t *out_ids, double *out_values);
 int vl_index_search_positions(const vl_index *h, const double *query, uint64_t q_len, uint64_t k, int metric,
                               uint64_t *out_pos, uint64_t *out_ids, double *out_scores, uint64_t *out_n);
 
+/* Batched form of vl_index_search_positions: out_pos/out_ids/out_scores are [nq, k], out_n is [nq]. */
+int vl_index_search_batch_positions(const vl_index *h, const double *queries, uint64_t nq, uint64_t q_len,
+                                    uint64_t k, int metric, uint64_t *out_pos, uint64_t *out_ids,
+                                    double *out_scores, uint64_t *out_n);
+
 /* ---- HNSW distance callbacks (src/index/hnsw.rs:113-174) ------------------ */
 
 /* For each of the m stored rows at `positions`, Metric::distance(query, row) -> u64

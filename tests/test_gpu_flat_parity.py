@@ -324,6 +324,54 @@ def test_search_batch_equals_single_searches(V, O):
             assert bn[i] == k and bi[i].tolist() == ri.tolist() and bs[i].tolist() == rs.tolist(), (name, i)
 
 
+@pytest.mark.parametrize("dim", [128, 384, 768, 100])
+def test_batch_scan_kernel_parity(V, O, dim):
+    """k_scan_batch (8 queries per slab pass) vs the oracle, including queries that must fall back:
+    duplicates at the cut, an out-of-domain query, a zero query; dim = 100 has no batch shape."""
+    rng = np.random.default_rng(100 + dim)
+    n, nq = 6000, 21
+    rows = unit_rows(rng, n, dim)
+    rows[4000:4040] = rows[17]  # 41 identical rows: a tie group wider than any k below
+    ids = permuted_ids(n)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    Q = unit_rows(rng, nq, dim)
+    Q[3] = rows[17]       # hits the tie group -> exact fallback for this query only
+    Q[5] = Q[5] * 1e100   # out of the f32 domain
+    Q[9] = 0.0            # zero query
+    for name, m in M.items():
+        for k in (1, 10, 32):
+            bi, bs, bn = gpu.search_batch(Q, k, m)
+            pos, pid, psc, pn = gpu.search_batch_positions(Q, k, m)
+            for i in range(nq):
+                ri, rs = ref.search(Q[i], k, m)
+                assert bn[i] == len(ri) and pn[i] == len(ri)
+                assert bi[i].tolist() == ri.tolist(), (dim, name, k, i)
+                assert bs[i].tolist() == rs.tolist(), (dim, name, k, i)
+                assert pid[i].tolist() == ri.tolist() and psc[i].tolist() == rs.tolist()
+                assert [int(ids[p]) for p in pos[i]] == ri.tolist()
+
+
+def test_sharded_index_single_rank_equals_flat(V, O):
+    from vectorlite_amd.sharded import ShardedFlatIndex
+    rng = np.random.default_rng(31)
+    n, dim = 5000, 384
+    rows = unit_rows(rng, n, dim)
+    ids = permuted_ids(n)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    sh = ShardedFlatIndex(gpu, offset=0)
+    Q = unit_rows(rng, 11, dim)
+    for m in range(4):
+        bi, bs, bn = sh.search_batch(Q, 10, m)
+        for i in range(11):
+            ri, rs = ref.search(Q[i], 10, m)
+            assert bi[i].tolist() == ri.tolist() and bs[i].tolist() == rs.tolist()
+    assert sh.global_len() == n
+
+
 def test_device_resident_ingest_matches_host_ingest(V, O):
     import torch
     rng = np.random.default_rng(2)

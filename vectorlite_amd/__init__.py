@@ -268,6 +268,21 @@ class FlatIndex:
                                              _pf64(scores), _pu64(n)))
         return ids[:, : int(k)], scores[:, : int(k)], n[:nq]
 
+    def search_batch_positions(self, queries, k: int, metric: int = 0):
+        """(positions, ids, scores, n), each [nq, k] ([nq] for n): the batched search_positions."""
+        Q = _f64(queries)
+        if Q.ndim != 2:
+            raise ValueError("queries must be [nq, dim]")
+        nq, qlen = Q.shape
+        kk = max(int(k), 1)
+        pos = np.zeros((nq, kk), dtype=np.uint64)
+        ids = np.zeros((nq, kk), dtype=np.uint64)
+        scores = np.zeros((nq, kk), dtype=np.float64)
+        n = np.zeros(max(nq, 1), dtype=np.uint64)
+        _raise(self._L.vl_index_search_batch_positions(self._h, _pf64(Q), nq, qlen, int(k), int(metric), _pu64(pos),
+                                                       _pu64(ids), _pf64(scores), _pu64(n)))
+        return pos[:, : int(k)], ids[:, : int(k)], scores[:, : int(k)], n[:nq]
+
     def add_rows(self, ids, values, validate: bool = True) -> None:
         """n x add() in one device pass.  `values`: [n, dim] f64 numpy array, or a torch CUDA/HIP
         tensor (f64, contiguous, on this index's device) which is ingested device-to-device."""

@@ -17,7 +17,7 @@ SYMBOLS = [
     "vl_flat_create", "vl_flat_from_rows", "vl_index_clone", "vl_index_destroy", "vl_index_reserve",
     "vl_index_add", "vl_index_add_bulk", "vl_index_delete", "vl_index_search", "vl_index_search_batch",
     "vl_index_len", "vl_index_is_empty", "vl_index_dimension", "vl_index_get_vector", "vl_index_max_id",
-    "vl_index_export", "vl_index_search_positions", "vl_index_hnsw_distances", "vl_hnsw_score",
+    "vl_index_export", "vl_index_search_positions", "vl_index_search_batch_positions", "vl_index_hnsw_distances", "vl_hnsw_score",
     "vl_last_error", "vl_last_dim_mismatch", "vl_last_path", "vl_index_force_path",
     "vl_index_profile_enable", "vl_index_profile_read", "vl_runtime_info",
 ]
@@ -66,6 +66,7 @@ def load() -> C.CDLL:
     sig("vl_index_max_id", i32, [vp, p_u64])
     sig("vl_index_export", i32, [vp, p_u64, p_f64])
     sig("vl_index_search_positions", i32, [vp, p_f64, u64, u64, i32, p_u64, p_u64, p_f64, p_u64])
+    sig("vl_index_search_batch_positions", i32, [vp, p_f64, u64, u64, u64, i32, p_u64, p_u64, p_f64, p_u64])
     sig("vl_index_hnsw_distances", i32, [vp, p_f64, u64, i32, p_u64, u64, p_u64])
     sig("vl_hnsw_score", f64, [u64, i32])
     sig("vl_last_error", C.c_char_p, [])

@@ -145,12 +145,17 @@ int vl_index_search_batch(const vl_index* h, const double* queries, uint64_t nq,
 {
     return guarded([&]() -> int {
         if (!h || (!out_n && nq)) return VL_ERR_INVALID_ARG;
-        for (uint64_t i = 0; i < nq; ++i) {
-            int rc = h->flat->search(queries + i * q_len, q_len, k, metric, nullptr, out_ids + i * k,
-                                     out_scores + i * k, out_n + i);
-            if (rc != VL_OK) return rc;
-        }
-        return VL_OK;
+        return h->flat->search_batch(queries, nq, q_len, k, metric, nullptr, out_ids, out_scores, out_n);
+    });
+}
+
+int vl_index_search_batch_positions(const vl_index* h, const double* queries, uint64_t nq, uint64_t q_len,
+                                    uint64_t k, int metric, uint64_t* out_pos, uint64_t* out_ids,
+                                    double* out_scores, uint64_t* out_n)
+{
+    return guarded([&]() -> int {
+        if (!h || (!out_n && nq)) return VL_ERR_INVALID_ARG;
+        return h->flat->search_batch(queries, nq, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
     });
 }
 

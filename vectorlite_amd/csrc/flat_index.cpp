@@ -349,14 +349,15 @@ int GpuFlatIndex::prepare_ws(Workspace* ws) const
 {
     ws->device = device_;
     VL_HIP(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
-    const size_t qn = std::max<size_t>(ld_, 4);
+    // staged queries: up to SCAN_BATCH_QB rows of dim f64, followed by their norms
+    const size_t qn = (size_t)SCAN_BATCH_QB * (dim_ + 1) + 8;
     ws->q_cap = qn;
     VL_TRY(dev_alloc(&ws->d_q64, qn));
     VL_TRY(pinned_alloc(&ws->h_q64, qn));
     VL_TRY(dev_alloc(&ws->d_partials, PARTIALS32_ENTRIES));
     VL_TRY(dev_alloc(&ws->d_partials64, PARTIALS64_ENTRIES));
     VL_TRY(dev_alloc(&ws->d_result, 1));
-    VL_TRY(pinned_alloc(&ws->h_result, 1));
+    VL_TRY(pinned_alloc(&ws->h_result, SCAN_BATCH_QB));
     VL_TRY(dev_alloc(&ws->d_nan, 1));
     VL_TRY(pinned_alloc(&ws->h_nan, 1));
     VL_HIP(hipEventCreate(&ws->ev0));
@@ -427,14 +428,135 @@ int GpuFlatIndex::search(const double* query, uint64_t q_len, uint64_t k, int me
     VL_HIP(hipSetDevice(device_));
     Workspace* ws = acquire_ws();
     if (!ws) return ERR_DEVICE;
-    const int rc = search_locked(ws, query, k_eff, metric, out_pos, out_ids, out_scores, out_n);
+    const int rc = search_locked(ws, query, k_eff, metric, out_pos, out_ids, out_scores, out_n, false);
     if (rc != OK) (void)hipStreamSynchronize(ws->stream);
     release_ws(ws);
     return rc;
 }
 
+// nq independent searches.  Groups of SCAN_BATCH_QB queries share ONE pass over the slab
+// (k_scan_batch); every query still gets its own exact rescoring, bound check and, if that fails,
+// its own exact-path run, so each row of the output is exactly what search() returns.
+int GpuFlatIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_len, uint64_t k, int metric,
+                               uint64_t* out_pos, uint64_t* out_ids, double* out_scores, uint64_t* out_n) const
+{
+    if (nq == 0) return OK;
+    if (!out_n) return ERR_INVALID_ARG;
+    for (uint64_t i = 0; i < nq; ++i) out_n[i] = 0;
+    if (metric < 0 || metric > 3) {
+        set_last_error("unknown metric");
+        return ERR_INVALID_ARG;
+    }
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    const uint64_t n = ids_.size();
+    if (n != 0 && q_len != dim_) {
+        set_dim_mismatch(dim_, q_len);
+        set_last_error("Dimension mismatch: expected " + std::to_string(dim_) + ", got " + std::to_string(q_len));
+        return ERR_DIM_MISMATCH;
+    }
+    if (n == 0 || k == 0) return OK;
+    if (!queries || !out_scores) return ERR_INVALID_ARG;
+    const uint64_t k_eff = std::min<uint64_t>(k, n);
+
+    VL_HIP(hipSetDevice(device_));
+    Workspace* ws = acquire_ws();
+    if (!ws) return ERR_DEVICE;
+    struct Releaser {
+        const GpuFlatIndex* self;
+        Workspace* ws;
+        ~Releaser()
+        {
+            (void)hipStreamSynchronize(ws->stream);
+            self->release_ws(ws);
+        }
+    } rel{this, ws};
+    hipStream_t st = ws->stream;
+
+    const bool batchable = nq > 1 && force_path_.load() == 0 && k_eff <= (uint64_t)KFAST_MAX &&
+                           n_out_of_domain_ == 0 && scan_batch_supported(ld_);
+    auto out_at = [&](uint64_t* base, uint64_t qi) { return base ? base + qi * k : nullptr; };
+    auto single = [&](uint64_t qi, bool skip_fast) -> int {
+        return search_locked(ws, queries + qi * dim_, k_eff, metric, out_at(out_pos, qi), out_at(out_ids, qi),
+                             out_scores + qi * k, out_n + qi, skip_fast);
+    };
+    if (!batchable) {
+        for (uint64_t qi = 0; qi < nq; ++qi) VL_TRY(single(qi, false));
+        return OK;
+    }
+
+    const bool prof = profile_.load();
+    for (uint64_t q0 = 0; q0 < nq; q0 += SCAN_BATCH_QB) {
+        const uint32_t g = (uint32_t)std::min<uint64_t>(SCAN_BATCH_QB, nq - q0);
+        bool in_domain[SCAN_BATCH_QB];
+        double* norms = ws->h_q64 + (size_t)g * dim_;
+        for (uint32_t j = 0; j < g; ++j) {
+            const double* q = queries + (q0 + j) * dim_;
+            double qq = 0.0, qmax = 0.0;
+            bool finite = true;
+            for (uint64_t i = 0; i < dim_; ++i) {
+                const double v = q[i];
+                ws->h_q64[(size_t)j * dim_ + i] = v;
+                qq += v * v;
+                const double av = std::fabs(v);
+                if (!(av <= 1.797693134862315708e308)) finite = false;
+                if (av > qmax) qmax = av;
+            }
+            norms[j] = std::sqrt(qq);
+            in_domain[j] = finite && qmax <= DOMAIN_MAX_ABS && (norms[j] == 0.0 || norms[j] >= DOMAIN_MIN_NORM);
+            if (!in_domain[j]) {  // keeps the f32 scan finite; this query is redone on the exact path
+                for (uint64_t i = 0; i < dim_; ++i) ws->h_q64[(size_t)j * dim_ + i] = 0.0;
+                norms[j] = 0.0;
+            }
+        }
+        VL_HIP(hipMemcpyAsync(ws->d_q64, ws->h_q64, ((size_t)g * dim_ + g) * sizeof(double), hipMemcpyHostToDevice, st));
+        ScanPlan plan;
+        if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
+        VL_HIP(launch_scan_batch(st, metric, d_slab_, d_inv_norm_, ws->d_q64, g, n, (uint32_t)dim_, ld_, ws->d_partials,
+                                 &plan));
+        if (prof) VL_HIP(hipEventRecord(ws->ev1, st));
+        VL_HIP(launch_merge_finalize(st, metric, ws->d_partials, plan.grid, (int)g, d_master_, ws->d_q64,
+                                     ws->d_q64 + (size_t)g * dim_, (uint32_t)dim_, n, (uint32_t)k_eff, max_row_norm_,
+                                     ws->h_result));
+        VL_HIP(hipStreamSynchronize(st));
+        if (prof) {
+            float ms = 0.f;
+            VL_HIP(hipEventElapsedTime(&ms, ws->ev0, ws->ev1));
+            std::lock_guard<std::mutex> gl(prof_mu_);
+            prof_n_ += 1;
+            prof_ms_ += ms;
+            prof_bytes_ += n * (uint64_t)ld_ * sizeof(float);
+        }
+        // copy the result blocks out first: a fallback below reuses the workspace
+        SearchResultBlock blocks[SCAN_BATCH_QB];
+        std::memcpy(blocks, ws->h_result, g * sizeof(SearchResultBlock));
+        for (uint32_t j = 0; j < g; ++j) {
+            const uint64_t qi = q0 + j;
+            const SearchResultBlock& r = blocks[j];
+            bool ok = in_domain[j] && !(r.flags & RESULT_NEEDS_EXACT) && r.n_out == k_eff;
+            if (ok) {
+                for (uint64_t i = 0; i < k_eff; ++i) {
+                    const uint32_t p = r.pos[i];
+                    if (p >= n) {
+                        set_last_error("batch fast path returned an out-of-range position (kernel bug)");
+                        return ERR_DEVICE;
+                    }
+                    if (out_pos) out_pos[qi * k + i] = p;
+                    if (out_ids) out_ids[qi * k + i] = ids_[p];
+                    out_scores[qi * k + i] = r.score[i];
+                }
+                out_n[qi] = k_eff;
+            } else {
+                VL_TRY(single(qi, true));
+            }
+        }
+        set_last_path(PATH_FAST);
+    }
+    return OK;
+}
+
 int GpuFlatIndex::search_locked(Workspace* ws, const double* query, uint64_t k_eff, int metric,
-                                uint64_t* out_pos, uint64_t* out_ids, double* out_scores, uint64_t* out_n) const
+                                uint64_t* out_pos, uint64_t* out_ids, double* out_scores, uint64_t* out_n,
+                                bool skip_fast) const
 {
     const uint64_t n = ids_.size();
     hipStream_t st = ws->stream;
@@ -452,11 +574,13 @@ int GpuFlatIndex::search_locked(Workspace* ws, const double* query, uint64_t k_e
     }
     const double q_norm = std::sqrt(qq);
     const bool q_in_domain = q_finite && qmax <= DOMAIN_MAX_ABS && (q_norm == 0.0 || q_norm >= DOMAIN_MIN_NORM);
-    // one small H2D copy per query; the scan kernel rounds its f32 copy of the query itself
-    VL_HIP(hipMemcpyAsync(ws->d_q64, ws->h_q64, dim_ * sizeof(double), hipMemcpyHostToDevice, st));
+    // one small H2D copy per query (the query and, behind it, its norm); the scan kernel rounds its
+    // f32 copy of the query itself
+    ws->h_q64[dim_] = q_norm;
+    VL_HIP(hipMemcpyAsync(ws->d_q64, ws->h_q64, (dim_ + 1) * sizeof(double), hipMemcpyHostToDevice, st));
 
     const int forced = force_path_.load();
-    const bool fast_ok = forced == 0 && dim_ > 0 && k_eff <= (uint64_t)KFAST_MAX && n_out_of_domain_ == 0 &&
+    const bool fast_ok = !skip_fast && forced == 0 && k_eff <= (uint64_t)KFAST_MAX && n_out_of_domain_ == 0 &&
                          q_in_domain;
     if (fast_ok) {
         const bool prof = profile_.load();
@@ -465,8 +589,9 @@ int GpuFlatIndex::search_locked(Workspace* ws, const double* query, uint64_t k_e
         VL_HIP(launch_scan(st, metric, d_slab_, d_inv_norm_, ws->d_q64, n, (uint32_t)dim_, ld_, ws->d_partials, &plan));
         if (prof) VL_HIP(hipEventRecord(ws->ev1, st));
         // the finalize kernel stores the 1 KB result block straight into pinned host memory
-        VL_HIP(launch_merge_finalize(st, metric, ws->d_partials, plan.grid, d_master_, ws->d_q64, (uint32_t)dim_,
-                                     n, (uint32_t)k_eff, max_row_norm_, q_norm, ws->h_result));
+        VL_HIP(launch_merge_finalize(st, metric, ws->d_partials, plan.grid, 1, d_master_, ws->d_q64,
+                                     ws->d_q64 + dim_, (uint32_t)dim_, n, (uint32_t)k_eff, max_row_norm_,
+                                     ws->h_result));
         VL_HIP(hipStreamSynchronize(st));
         if (prof) {
             float ms = 0.f;

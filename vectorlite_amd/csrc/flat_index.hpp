@@ -87,6 +87,10 @@ public:
     int remove(uint64_t id);  // `delete`
     int search(const double* query, uint64_t q_len, uint64_t k, int metric, uint64_t* out_pos,
                uint64_t* out_ids, double* out_scores, uint64_t* out_n) const;
+    // NEW (no reference counterpart): nq independent searches sharing slab passes; outputs are
+    // [nq, k] with row stride k.
+    int search_batch(const double* queries, uint64_t nq, uint64_t q_len, uint64_t k, int metric, uint64_t* out_pos,
+                     uint64_t* out_ids, double* out_scores, uint64_t* out_n) const;
     uint64_t len() const;
     bool is_empty() const { return len() == 0; }
     uint64_t dimension() const { return dim_; }
@@ -114,7 +118,7 @@ private:
     void release_ws(Workspace* ws) const;
     int prepare_ws(Workspace* ws) const;
     int search_locked(Workspace* ws, const double* query, uint64_t k_eff, int metric, uint64_t* out_pos,
-                      uint64_t* out_ids, double* out_scores, uint64_t* out_n) const;
+                      uint64_t* out_ids, double* out_scores, uint64_t* out_n, bool skip_fast) const;
     int run_exact(Workspace* ws, int metric, uint64_t n, uint64_t k_eff, std::vector<uint32_t>* pos,
                   std::vector<double>* scores) const;
 

@@ -195,15 +195,18 @@ __device__ __forceinline__ void fold_lists4(TopList<K>& L, const C* __restrict__
     L.thr_pos = read_lane(L.pos, WAVE - 1);
 }
 
-// Merge level: workgroup b folds lists [64b, 64b+64) (16 waves x 4 lists, then a 4-level tree)
-// into one sorted list out[b].
+// Merge level: workgroup (b, q) folds lists [64b, 64b+64) of query q (16 waves x 4 lists, then a
+// 4-level tree) into one sorted list out[q][b].
 template <typename K, typename C>
-__global__ __launch_bounds__(1024) void k_merge_lists(const C* __restrict__ lists, int n_lists, C* __restrict__ out)
+__global__ __launch_bounds__(1024) void k_merge_lists(const C* __restrict__ lists, int n_lists, size_t in_stride_q,
+                                                      C* __restrict__ out, size_t out_stride_q)
 {
     constexpr int NW = 16;
     __shared__ C sh[NW * WAVE];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
+    lists += (size_t)blockIdx.y * in_stride_q;
+    out += (size_t)blockIdx.y * out_stride_q;
     const int first = blockIdx.x * 64 + wave * 4;
     int count = n_lists - first;
     count = count < 0 ? 0 : (count > 4 ? 4 : count);
@@ -379,6 +382,77 @@ __global__ __launch_bounds__(256) void k_scan_generic(const f32x4* __restrict__ 
     }
 }
 
+// K3: small-batch scan.  One pass over the slab serves QB queries: each row group is loaded ONCE into
+// registers and scored against QB queries whose f32 copies sit in LDS (lanes that share a column read
+// the same 16 bytes: an LDS broadcast).  Per wave, QB independent top-64 lists.  Still streams
+// N*ld*4 bytes per pass; with QB = 8 the f32 VALU work (2*QB flop per 4 bytes) is about level with
+// the HBM time, beyond that the GEMM/MFMA form takes over.
+template <int METRIC, int G, int VPL, int QB>
+__global__ __launch_bounds__(256) void k_scan_batch(const f32x4* __restrict__ slab, const float* __restrict__ inv_norm,
+                                                    const double* __restrict__ q64, uint32_t n_q, uint32_t dim,
+                                                    uint32_t n, Cand32* __restrict__ out)
+{
+    constexpr int RPS = WAVE / G;
+    constexpr uint32_t LD4 = G * VPL;
+    __shared__ f32x4 qs[QB][LD4];
+    __shared__ Cand32 sh[4 * WAVE];
+
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int g = lane / G, c = lane % G;
+
+    for (uint32_t idx = threadIdx.x; idx < QB * LD4; idx += 256) {
+        const uint32_t qi = idx / LD4, j = idx % LD4;
+        f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        qs[qi][j] = qi < n_q ? load_q4(q64 + (size_t)qi * dim, j, dim) : z;
+    }
+    __syncthreads();
+
+    const uint32_t n_steps = (n + RPS - 1) / RPS;
+    const uint32_t n_waves = gridDim.x * 4;
+
+    TopList<float> L[QB];
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) L[qi].init();
+
+    for (uint32_t s = blockIdx.x * 4 + wave; s < n_steps; s += n_waves) {
+        const uint32_t row = s * RPS + g;
+        const bool valid = row < n;
+        const uint32_t r = valid ? row : n - 1;
+        const f32x4* p = slab + (size_t)r * LD4 + c;
+        f32x4 x[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) x[j] = __builtin_nontemporal_load(p + G * j);
+        float inv = 1.0f;
+        if (METRIC == COSINE) inv = inv_norm[r];
+#pragma unroll
+        for (int qi = 0; qi < QB; ++qi) {
+            float a = 0.0f;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) a = acc4<METRIC>(a, x[j], qs[qi][c + G * j]);
+            a = group_reduce<G>(a);
+            L[qi].offer(scan_key<METRIC>(a, inv), row, valid && c == 0 && (uint32_t)qi < n_q);
+            // one query's LDS reads at a time: without this the scheduler hoists every query's
+            // 48 registers of LDS loads above the first FMA and the kernel needs 460+ VGPRs
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) {
+        if ((uint32_t)qi < n_q) {  // uniform
+            block_merge<float, Cand32, 4>(L[qi], sh);
+            if (wave == 0) {
+                Cand32 e;
+                e.key = L[qi].key;
+                e.pos = L[qi].pos;
+                out[((size_t)qi * gridDim.x + blockIdx.x) * KP + lane] = e;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Reference-order f64 arithmetic (this TU is built with -ffp-contract=off: `a += x * y` is one
 // rounded multiply followed by one rounded add, like rustc's output for src/lib.rs:425-572).
@@ -517,11 +591,17 @@ __device__ __forceinline__ double bound_for_key(float t_key, uint32_t n, double 
 // K2: merge partial lists, rescore, rank, bound-check.  One workgroup of 1024 threads.
 template <int METRIC>
 __global__ __launch_bounds__(1024) void k_merge_finalize(const Cand32* __restrict__ partials, int n_lists,
-                                                         const double* __restrict__ master,
-                                                         const double* __restrict__ q64, uint32_t dim,
+                                                         size_t list_stride_q, const double* __restrict__ master,
+                                                         const double* __restrict__ q64,
+                                                         const double* __restrict__ q_norms, uint32_t dim,
                                                          uint32_t ld, uint64_t n_rows, uint32_t k, double R,
-                                                         double Q, SearchResultBlock* __restrict__ out)
+                                                         SearchResultBlock* __restrict__ out)
 {
+    // one workgroup per query of the batch
+    partials += (size_t)blockIdx.x * list_stride_q;
+    q64 += (size_t)blockIdx.x * dim;
+    out += blockIdx.x;
+    const double Q = q_norms[blockIdx.x];
     constexpr int NW = 16;
     __shared__ Cand32 sh_lists[NW * WAVE];
     __shared__ double tile[KP][RESCORE_CH + 1];
@@ -1059,38 +1139,94 @@ hipError_t launch_scan(hipStream_t s, int metric, const float* slab, const float
     return rc;
 }
 
+// Batch shapes: one (G, VPL) per supported row length, QB = 8 queries per pass.
+#define VL_BATCH_SHAPES(X) X(8, 4) X(8, 8) X(8, 12) X(8, 16) X(16, 12) X(16, 16) X(16, 24)
+
+bool scan_batch_supported(uint32_t ld)
+{
+    const uint32_t ld4 = ld / 4;
+    bool ok = false;
+#define VL_CHK(G, VPL) ok = ok || ((uint32_t)(G * VPL) == ld4);
+    VL_BATCH_SHAPES(VL_CHK)
+#undef VL_CHK
+    return ok && (ld % 4) == 0;
+}
+
+hipError_t launch_scan_batch(hipStream_t s, int metric, const float* slab, const float* inv_norm, const double* q64,
+                             uint32_t nq, uint64_t n, uint32_t dim, uint32_t ld, Cand32* partials, ScanPlan* plan)
+{
+    if (n == 0 || n >= 0xFFFFFFFFull || (ld & 3) || nq == 0 || nq > (uint32_t)SCAN_BATCH_QB) return hipErrorInvalidValue;
+    const uint32_t ld4 = ld / 4;
+    const f32x4* slab4 = reinterpret_cast<const f32x4*>(slab);
+    const uint32_t n32 = (uint32_t)n;
+    int grid = 0;
+    hipError_t rc = dispatch_metric(metric, [&](auto M) -> hipError_t {
+        constexpr int MM = decltype(M)::value;
+        bool launched = false;
+#define VL_TRY_BATCH(G, VPL)                                                                                  \
+    if (!launched && (uint32_t)(G * VPL) == ld4) {                                                            \
+        auto kern = k_scan_batch<MM, G, VPL, SCAN_BATCH_QB>;                                                  \
+        int cus = 0;                                                                                          \
+        const int resident = resident_blocks(reinterpret_cast<const void*>(kern), &cus);                      \
+        const uint64_t steps = (n + (64 / G) - 1) / (64 / G);                                                 \
+        uint64_t blocks = (steps + 3) / 4;                                                                    \
+        uint64_t cap = (uint64_t)env_int("VL_BATCH_GRID", 0);                                                 \
+        if (cap == 0) cap = (uint64_t)resident;                                                               \
+        if (cap > (uint64_t)SCAN_BATCH_MAX_GRID) cap = SCAN_BATCH_MAX_GRID;                                   \
+        if (blocks > cap) blocks = cap;                                                                       \
+        grid = (int)(blocks < 1 ? 1 : blocks);                                                                \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, slab4, inv_norm, q64, nq, dim, n32, partials);  \
+        launched = true;                                                                                      \
+    }
+        VL_BATCH_SHAPES(VL_TRY_BATCH)
+#undef VL_TRY_BATCH
+        if (!launched) return hipErrorInvalidValue;
+        return hipGetLastError();
+    });
+    if (plan) {
+        plan->grid = grid;
+        plan->variant = 0;
+    }
+    return rc;
+}
+
 namespace {
-// Reduce n_lists sorted lists to <= 64 with merge levels; `scratch` holds two ping-pong regions of
-// 64 lists each.  Returns the final list array and count.
+// Reduce n_lists sorted lists per query to <= 64 with merge levels.  `scratch` holds two ping-pong
+// regions of nq x 64 lists.  Returns the final list array, count and per-query stride.
 template <typename K, typename C>
-const C* reduce_lists(hipStream_t s, const C* lists, int* n_lists, C* scratch)
+const C* reduce_lists(hipStream_t s, const C* lists, int* n_lists, size_t* stride_q, int nq, C* scratch)
 {
     int n = *n_lists;
+    size_t in_stride = *stride_q;
     int ping = 0;
     while (n > 64) {
         const int blocks = (n + 63) / 64;
-        C* out = scratch + (size_t)ping * 64 * KP;
-        hipLaunchKernelGGL((k_merge_lists<K, C>), dim3(blocks), dim3(1024), 0, s, lists, n, out);
+        const size_t out_stride = (size_t)64 * KP;
+        C* out = scratch + (size_t)ping * nq * out_stride;
+        hipLaunchKernelGGL((k_merge_lists<K, C>), dim3(blocks, nq), dim3(1024), 0, s, lists, n, in_stride, out,
+                           out_stride);
         lists = out;
+        in_stride = out_stride;
         n = blocks;
         ping ^= 1;
     }
     *n_lists = n;
+    *stride_q = in_stride;
     return lists;
 }
 }  // namespace
 
-hipError_t launch_merge_finalize(hipStream_t s, int metric, Cand32* partials, int n_lists,
-                                 const double* master, const double* q64, uint32_t dim, uint64_t n_rows,
-                                 uint32_t k, double max_row_norm, double q_norm, SearchResultBlock* out)
+hipError_t launch_merge_finalize(hipStream_t s, int metric, Cand32* partials, int n_lists, int nq,
+                                 const double* master, const double* q64, const double* q_norms, uint32_t dim,
+                                 uint64_t n_rows, uint32_t k, double max_row_norm, SearchResultBlock* out)
 {
     const uint32_t ld = (dim + 3u) & ~3u;
-    const Cand32* lists = reduce_lists<float, Cand32>(s, partials, &n_lists, partials + (size_t)SCAN_MAX_GRID * KP);
-    partials = const_cast<Cand32*>(lists);
+    size_t stride = (size_t)n_lists * KP;
+    const Cand32* lists = reduce_lists<float, Cand32>(s, partials, &n_lists, &stride, nq, partials + PARTIALS32_LISTS * KP);
     return dispatch_metric(metric, [&](auto M) -> hipError_t {
         constexpr int MM = decltype(M)::value;
-        hipLaunchKernelGGL((k_merge_finalize<MM>), dim3(1), dim3(1024), 0, s, partials, n_lists, master, q64, dim,
-                           ld, n_rows, k, max_row_norm, q_norm, out);
+        hipLaunchKernelGGL((k_merge_finalize<MM>), dim3(nq), dim3(1024), 0, s, lists, n_lists, stride, master, q64,
+                           q_norms, dim, ld, n_rows, k, max_row_norm, out);
         return hipGetLastError();
     });
 }
@@ -1126,7 +1262,8 @@ hipError_t launch_exact_select(hipStream_t s, const double* scores, uint64_t n, 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     int n_lists = grid;
-    const Cand64* lists = reduce_lists<double, Cand64>(s, partials, &n_lists, partials + (size_t)SELECT_MAX_GRID * KP);
+    size_t stride = (size_t)n_lists * KP;
+    const Cand64* lists = reduce_lists<double, Cand64>(s, partials, &n_lists, &stride, 1, partials + (size_t)SELECT_MAX_GRID * KP);
     hipLaunchKernelGGL(k_merge64_emit, dim3(1), dim3(1024), 0, s, lists, n_lists, n, k, nan_flag, out);
     return hipGetLastError();
 }

@@ -60,8 +60,13 @@ hipError_t launch_ingest(hipStream_t s, const double* master, float* slab, float
 // Upper bound on the workgroups launch_scan uses (partials must hold SCAN_MAX_GRID*KP entries).
 constexpr int SCAN_MAX_GRID = 4096;
 constexpr int SELECT_MAX_GRID = 1024;
-// partial-list buffers hold the scan/select lists plus two 64-list merge regions
-constexpr size_t PARTIALS32_ENTRIES = (size_t)(SCAN_MAX_GRID + 128) * KP;
+constexpr int SCAN_BATCH_QB = 8;           // queries served by one slab pass of k_scan_batch
+constexpr int SCAN_BATCH_MAX_GRID = 2048;
+// partial-list buffers: the scan lists (single: SCAN_MAX_GRID; batch: QB x SCAN_BATCH_MAX_GRID),
+// followed by two ping-pong merge regions of QB x 64 lists
+constexpr size_t PARTIALS32_LISTS = (size_t)SCAN_BATCH_QB * SCAN_BATCH_MAX_GRID;
+static_assert(PARTIALS32_LISTS >= (size_t)SCAN_MAX_GRID, "single-query lists must fit");
+constexpr size_t PARTIALS32_ENTRIES = (PARTIALS32_LISTS + 2 * (size_t)SCAN_BATCH_QB * 64) * KP;
 constexpr size_t PARTIALS64_ENTRIES = (size_t)(SELECT_MAX_GRID + 128) * KP;
 
 // K1: f32 slab scan -> per-workgroup top-KP partial lists.
@@ -71,9 +76,16 @@ hipError_t launch_scan(hipStream_t s, int metric, const float* slab, const float
 // `out` may be pinned host memory (the result block is written once, by one wave).
 // K2: merge partial lists -> top-KP, rescore them in reference f64 arithmetic from the master
 // rows, rank by (score desc, pos asc), run the exactness bound check, write the result block.
-hipError_t launch_merge_finalize(hipStream_t s, int metric, Cand32* partials, int n_lists,
-                                 const double* master, const double* q64, uint32_t dim, uint64_t n_rows,
-                                 uint32_t k, double max_row_norm, double q_norm, SearchResultBlock* out);
+// One workgroup per query: `partials` holds nq x n_lists lists (query-major), q64 is [nq, dim],
+// q_norms[nq] the f64 query norms, out[nq] the result blocks.
+hipError_t launch_merge_finalize(hipStream_t s, int metric, Cand32* partials, int n_lists, int nq,
+                                 const double* master, const double* q64, const double* q_norms, uint32_t dim,
+                                 uint64_t n_rows, uint32_t k, double max_row_norm, SearchResultBlock* out);
+
+// K3: one slab pass for nq <= SCAN_BATCH_QB queries (q64 is [nq, dim]); lists are written query-major.
+bool scan_batch_supported(uint32_t ld);
+hipError_t launch_scan_batch(hipStream_t s, int metric, const float* slab, const float* inv_norm, const double* q64,
+                             uint32_t nq, uint64_t n, uint32_t dim, uint32_t ld, Cand32* partials, ScanPlan* plan);
 
 // Exact path: reference-order f64 score of every row.
 hipError_t launch_exact_scan(hipStream_t s, int metric, const double* master, const double* q64, uint64_t n,

@@ -92,15 +92,23 @@ class ShardedFlatIndex:
         kk = max(int(k), 1)
         # per query: kk rows of (score bits, global pos, id bits) + 1 row whose first word is the count
         packed = np.zeros((nq, kk + 1, 3), dtype=np.int64)
-        for qi in range(nq):
-            if len(self.local) == 0 or k == 0:
-                continue
-            pos, ids, scores = self.local.search_positions(Q[qi], k, metric)
-            c = len(pos)
-            packed[qi, :c, 0] = np.asarray(scores, dtype=np.float64).view(np.int64)
-            packed[qi, :c, 1] = np.asarray(pos, dtype=np.int64) + self.offset
-            packed[qi, :c, 2] = np.asarray(ids, dtype=np.uint64).view(np.int64)
-            packed[qi, kk, 0] = c
+        if len(self.local) != 0 and k != 0:
+            if hasattr(self.local, "search_batch_positions"):  # GPU shard: queries share slab passes
+                bpos, bids, bsc, bn = self.local.search_batch_positions(Q, k, metric)
+                for qi in range(nq):
+                    c = int(bn[qi])
+                    packed[qi, :c, 0] = np.ascontiguousarray(bsc[qi, :c]).view(np.int64)
+                    packed[qi, :c, 1] = bpos[qi, :c].astype(np.int64) + self.offset
+                    packed[qi, :c, 2] = np.ascontiguousarray(bids[qi, :c]).view(np.int64)
+                    packed[qi, kk, 0] = c
+            else:
+                for qi in range(nq):
+                    pos, ids, scores = self.local.search_positions(Q[qi], k, metric)
+                    c = len(pos)
+                    packed[qi, :c, 0] = np.asarray(scores, dtype=np.float64).view(np.int64)
+                    packed[qi, :c, 1] = np.asarray(pos, dtype=np.int64) + self.offset
+                    packed[qi, :c, 2] = np.asarray(ids, dtype=np.uint64).view(np.int64)
+                    packed[qi, kk, 0] = c
         gathered = self._all_gather(packed.reshape(-1)).reshape(self.world, nq, kk + 1, 3)
         out_ids = np.zeros((nq, kk), dtype=np.uint64)
         out_scores = np.zeros((nq, kk), dtype=np.float64)
