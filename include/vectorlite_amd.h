@@ -71,6 +71,19 @@ int vl_flat_create(uint64_t dim, int device, vl_index **out);
 int vl_flat_from_rows(uint64_t dim, const uint64_t *ids, const double *values, uint64_t n, int device,
                       vl_index **out);
 
+/* HNSWIndex::new(dim, metric) (src/index/hnsw.rs:216-259), default cargo profile M = 16, M0 = 32
+ * (src/index/hnsw.rs:95-109).  The handle then behaves like VectorIndexWrapper::HNSW
+ * (src/lib.rs:271-327) under every vl_index_* trait entry point below: add validates dimension and
+ * duplicate ids (:363-371), delete of an absent id is VL_ERR_NOT_FOUND (:401-403) and tombstones the
+ * node (:405-411), search checks the dimension even when empty (:416-421), rejects another metric with
+ * VL_ERR_METRIC_MISMATCH (:425-430), walks the graph with ef = min(k, len) (:437,454), converts
+ * u64 distances to scores (:51-75, :478-479), stable-sorts and truncates (:493-494).
+ * The graph walk itself is this library's own (crate hnsw 0.11.0 is not part of the reference tree):
+ * results are approximate and judged by recall. */
+int vl_hnsw_create(uint64_t dim, int metric, int device, vl_index **out);
+int vl_hnsw_create_ex(uint64_t dim, int metric, uint32_t m, uint32_t m0, uint32_t ef_construction, uint64_t seed,
+                      int device, vl_index **out);
+
 /* #[derive(Clone)] (src/index/flat.rs:59; persistence clones the index, src/persistence.rs:118). */
 int vl_index_clone(const vl_index *h, vl_index **out);
 
@@ -111,6 +124,16 @@ int vl_index_search_batch(const vl_index *h, const double *queries, uint64_t nq,
 uint64_t vl_index_len(const vl_index *h);      /* len()       src/index/flat.rs:121-123 */
 int vl_index_is_empty(const vl_index *h);      /* is_empty()  src/index/flat.rs:125-127 */
 uint64_t vl_index_dimension(const vl_index *h);/* dimension() src/index/flat.rs:133-135 */
+
+/* VectorIndexWrapper::index_type() / ::metric() (src/lib.rs:329-346): 0 = Flat, 1 = HNSW;
+ * vl_index_metric returns VL_ERR_NOT_FOUND for None (flat). */
+int vl_index_type(const vl_index *h);
+int vl_index_metric(const vl_index *h, int *out_metric);
+
+/* HNSW only, own extension (the reference has no ef knob): nq walks with beam width
+ * max(ef, min(k, len)); outputs as vl_index_search_batch. */
+int vl_index_search_ef(const vl_index *h, const double *queries, uint64_t nq, uint64_t q_len, uint64_t k,
+                       uint32_t ef, int metric, uint64_t *out_ids, double *out_scores, uint64_t *out_n);
 
 /* get_vector(id) (src/index/flat.rs:129-131): first row with that id -> out[dim];
  * VL_ERR_NOT_FOUND stands for None. */

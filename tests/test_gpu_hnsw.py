@@ -1,0 +1,167 @@
+"""GPU tests of the HNSW index: the reference's wrapper semantics (errors, tombstones, ef rule,
+u64 distances, score conversion) exactly; the graph walk (own traversal, parity unpinned) by recall."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+M = {"cosine": 0, "euclidean": 1, "manhattan": 2, "dotproduct": 3}
+
+
+@pytest.fixture(scope="module")
+def V():
+    import vectorlite_amd as V
+    assert V.runtime_info()[0] > 0
+    return V
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+def unit_rows(rng, n, dim):
+    x = rng.standard_normal((n, dim))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x
+
+
+def test_reference_hnsw_fixtures(V, kats):
+    for kat in kats["hnsw_search_kats"]:
+        idx = V.HNSWIndex(kat["dim"], M[kat["metric"]])
+        for i, r in zip(kat["ids"], kat["rows"]):
+            idx.add(V.Vector(i, r, "test"))
+        res = idx.search(kat["query"], kat["k"], M[kat["metric"]])
+        if kat.get("empty"):
+            assert res == []
+            continue
+        assert len(res) >= 1 and len(res) <= kat["max_len"], kat["src"]
+        assert all(res[i - 1].score >= res[i].score for i in range(1, len(res)))
+        if "first_id" in kat:
+            assert res[0].id == kat["first_id"], kat["src"]
+
+
+def test_survey_9_6_hnsw_rows(V):
+    """src/index/hnsw.rs:605-634: d_u64 = 173, 1424, 1424, 911 -> ids [100, 400] with these scores."""
+    idx = V.HNSWIndex(3, 1)
+    for i, r in ((100, [1, 0, 0]), (200, [0, 1, 0]), (300, [0, 0, 1]), (400, [1, 1, 0])):
+        idx.add(V.Vector(i, r))
+    res = idx.search([1.1, 0.1, 0.1], 2, 1)
+    assert [r.id for r in res] == [100, 400]
+    assert res[0].score == pytest.approx(0.85251491901108267, abs=1e-15)
+    assert res[1].score == pytest.approx(0.52328623757195181, abs=1e-15)
+    assert idx.get_vector(100).values == [1.0, 0.0, 0.0] and idx.get_vector(999) is None
+    assert idx.metric() == V.SimilarityMetric.Euclidean and idx.max_id() == 400
+
+
+def test_wrapper_errors_and_tombstones(V):
+    idx = V.HNSWIndex(3, 1)
+    assert idx.is_empty() and idx.dimension() == 3
+    with pytest.raises(V.DimensionMismatch) as e:  # checked even when empty (src/index/hnsw.rs:416-421)
+        idx.search([1, 2], 1, 1)
+    assert (e.value.expected, e.value.actual) == (3, 2)
+    assert idx.search([1, 2, 3], 5, 1) == []
+    idx.add(V.Vector(1, [1, 2, 3]))
+    with pytest.raises(V.IndexOpError, match="Vector ID 1 already exists"):
+        idx.add(V.Vector(1, [4, 5, 6]))
+    with pytest.raises(V.IndexOpError, match="Vector dimension mismatch: expected 3, got 2"):
+        idx.add(V.Vector(2, [1, 2]))
+    assert len(idx) == 1
+    with pytest.raises(V.MetricMismatch):  # src/index/hnsw.rs:425-430
+        idx.search([1, 2, 3], 1, 0)
+    with pytest.raises(V.IndexOpError, match="Vector ID 9 does not exist"):
+        idx.delete(9)
+    idx.add(V.Vector(2, [1, 2, 3.5]))
+    idx.add(V.Vector(3, [9, 9, 9]))
+    assert [r.id for r in idx.search([1, 2, 3], 10, 1)] == [1, 2, 3]  # k > len
+    idx.delete(1)
+    assert len(idx) == 2 and idx.get_vector(1) is None
+    # ef = min(k, len) = 1: the walk returns the tombstoned node, which is dropped afterwards (:475)
+    assert idx.search([1, 2, 3], 1, 1) == []
+    assert [r.id for r in idx.search([1, 2, 3], 2, 1)] == [2]
+    idx.add(V.Vector(1, [1, 2, 3]))  # the id can be reused after a delete; the tombstoned twin stays in the graph
+    assert [r.id for r in idx.search([1, 2, 3], 2, 1)] == [1]
+    assert len(idx) == 3
+
+
+@pytest.mark.parametrize("metric", ["cosine", "euclidean", "manhattan", "dotproduct"])
+def test_scores_are_the_reference_conversion_of_exact_u64_distances(V, O, metric):
+    m = M[metric]
+    rng = np.random.default_rng(10 + m)
+    n, dim = 3000, 48
+    rows = unit_rows(rng, n, dim) * (3.0 if metric != "cosine" else 1.0)
+    ids = np.arange(n, dtype=np.uint64) + 10_000
+    idx = V.HNSWIndex(dim, m)
+    idx.add_rows(ids, rows)
+    for qi in range(5):
+        q = unit_rows(rng, 1, dim)[0] * (3.0 if metric != "cosine" else 1.0)
+        gi, gs = idx.search_arrays(q, 10, m)
+        assert len(gi) == 10
+        want = [O.hnsw_score(O.hnsw_distance(m, q, rows[int(i) - 10_000]), m) for i in gi]
+        assert gs.tolist() == want
+        assert all(gs[i - 1] >= gs[i] for i in range(1, len(gs)))
+
+
+def _recall(O, m, q, rows, got_ids, k):
+    d = np.array([O.hnsw_distance(m, q, r) for r in rows], dtype=np.uint64)
+    kth = np.sort(d)[k - 1]
+    return sum(1 for i in got_ids if d[int(i)] <= kth) / float(k)
+
+
+def latent_rows(rng, n, dim, latent, A=None):
+    """Rows with low intrinsic dimension (A z + noise), like real embeddings; i.i.d. gaussian rows in
+    hundreds of dimensions are near-equidistant and defeat every graph index."""
+    if A is None:
+        A = rng.standard_normal((latent, dim))
+    x = rng.standard_normal((n, latent)) @ A + 0.05 * rng.standard_normal((n, dim))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x, A
+
+
+@pytest.mark.parametrize("metric,dim,n,latent", [("cosine", 384, 6000, 16), ("euclidean", 64, 8000, 12),
+                                                   ("manhattan", 48, 5000, 8), ("dotproduct", 96, 5000, 12)])
+def test_recall_of_the_walk(V, O, metric, dim, n, latent):
+    m = M[metric]
+    rng = np.random.default_rng(dim + n)
+    rows, A = latent_rows(rng, n, dim, latent)
+    idx = V.HNSWIndex(dim, m)
+    idx.add_rows(np.arange(n, dtype=np.uint64), rows)
+    assert len(idx) == n
+    r_ref, r_wide = [], []
+    Q, _ = latent_rows(rng, 20, dim, latent, A)
+    bi, bs, bn = idx.search_batch(Q, 10, m, ef=128)
+    for qi in range(20):
+        gi, _ = idx.search_arrays(Q[qi], 10, m)            # the reference's rule: ef = k = 10
+        r_ref.append(_recall(O, m, Q[qi], rows, gi, 10))
+        assert bn[qi] == 10
+        r_wide.append(_recall(O, m, Q[qi], rows, bi[qi], 10))
+    assert np.mean(r_wide) >= 0.95, (np.mean(r_ref), np.mean(r_wide))
+    assert np.mean(r_ref) >= 0.6, np.mean(r_ref)
+
+
+def test_walk_on_iid_gaussian_rows_still_finds_most(V, O):
+    rng = np.random.default_rng(5)
+    n, dim = 4000, 32
+    rows = unit_rows(rng, n, dim)
+    idx = V.HNSWIndex(dim, 0)
+    idx.add_rows(np.arange(n, dtype=np.uint64), rows)
+    Q = unit_rows(rng, 20, dim)
+    bi, _, _ = idx.search_batch(Q, 10, 0, ef=128)
+    assert np.mean([_recall(O, 0, Q[i], rows, bi[i], 10) for i in range(20)]) >= 0.9
+
+
+def test_incremental_adds_match_bulk_semantics(V, O):
+    rng = np.random.default_rng(3)
+    n, dim = 600, 16
+    rows = unit_rows(rng, n, dim)
+    idx = V.HNSWIndex(dim, 1)
+    for i in range(n):
+        idx.add(V.Vector(i * 7, rows[i]))
+    assert len(idx) == n
+    q = rows[123] + 1e-3
+    res = idx.search(q, 5, 1)
+    assert res[0].id == 123 * 7
+    with pytest.raises(V.IndexOpError):
+        idx.add_rows([5000, 7], rows[:2])  # second id exists: first row is kept, like sequential adds
+    assert len(idx) == n + 1

@@ -25,7 +25,7 @@ import numpy as np
 from . import _lib
 
 __all__ = [
-    "SimilarityMetric", "Vector", "SearchResult", "FlatIndex", "VectorLiteError", "DimensionMismatch",
+    "SimilarityMetric", "Vector", "SearchResult", "FlatIndex", "HNSWIndex", "VectorLiteError", "DimensionMismatch",
     "MetricMismatch", "NaNScore", "DeviceError", "IndexOpError", "hnsw_score", "runtime_info",
     "PATH_FAST", "PATH_EXACT_SELECT", "PATH_EXACT_SORT",
 ]
@@ -353,3 +353,143 @@ class FlatIndex:
         n, ms, b = C.c_uint64(0), C.c_double(0.0), C.c_uint64(0)
         _raise(self._L.vl_index_profile_read(self._h, C.byref(n), C.byref(ms), C.byref(b)))
         return n.value, ms.value, b.value
+
+
+class HNSWIndex:
+    """GPU counterpart of `HNSWIndex` (src/index/hnsw.rs:197-496), default profile M = 16, M0 = 32.
+
+    The distance callbacks (u64 = trunc(dist * 1000)), the score conversion, ef = min(k, len), the
+    tombstone deletes and every error are the reference's; the graph walk is this library's own
+    (crate hnsw 0.11.0 is not in the reference tree), so results are approximate: judged by recall."""
+
+    def __init__(self, dim: int, metric: int = SimilarityMetric.Cosine, device: int = 0, m: int = 16, m0: int = 32,
+                 ef_construction: int = 128, seed: int = 0):
+        self._L = _lib.load()
+        self._meta: Dict[int, Tuple[str, Any]] = {}
+        self._h = C.c_void_p()
+        self.device = device
+        if dim == 0:
+            raise ValueError("HNSW index dimension cannot be 0")  # panics in the reference (:217-219)
+        _raise(self._L.vl_hnsw_create_ex(dim, int(metric), m, m0, ef_construction, seed, device, C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self._L.vl_index_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def metric(self) -> SimilarityMetric:
+        m = C.c_int(0)
+        _raise(self._L.vl_index_metric(self._h, C.byref(m)))
+        return SimilarityMetric(m.value)
+
+    def add(self, vector: Vector) -> None:
+        vals = _f64(vector.values).ravel()
+        rc = self._L.vl_index_add(self._h, int(vector.id), _pf64(vals), vals.size)
+        if rc in (VL_ERR_DIM_MISMATCH, VL_ERR_DUP_ID):
+            raise IndexOpError(_last_error())
+        _raise(rc)
+        self._meta[int(vector.id)] = (vector.text, vector.metadata)
+
+    def add_rows(self, ids, values) -> None:
+        ids = np.ascontiguousarray(np.asarray(ids, dtype=np.uint64))
+        on_device = False
+        try:
+            import torch
+            is_tensor = isinstance(values, torch.Tensor)
+        except Exception:  # pragma: no cover
+            is_tensor = False
+        if is_tensor and values.is_cuda:
+            import torch
+            if values.dtype != torch.float64 or not values.is_contiguous():
+                raise ValueError("device rows must be a contiguous float64 tensor")
+            torch.cuda.current_stream(values.device).synchronize()
+            ptr, on_device = C.c_void_p(values.data_ptr()), True
+            count = values.numel()
+        else:
+            vals = _f64(values.numpy() if is_tensor else values)
+            ptr, count = C.c_void_p(vals.ctypes.data), vals.size
+        if count != ids.size * self.dimension():
+            raise ValueError("values must be [n, dim]")
+        rc = self._L.vl_index_add_bulk(self._h, _pu64(ids), ptr, ids.size, 1, 1 if on_device else 0)
+        if rc == VL_ERR_DUP_ID:
+            raise IndexOpError(_last_error())
+        _raise(rc)
+
+    def delete(self, id: int) -> None:
+        rc = self._L.vl_index_delete(self._h, int(id))
+        if rc == VL_ERR_NOT_FOUND:
+            raise IndexOpError(_last_error())  # "Vector ID {id} does not exist" (:401-403)
+        _raise(rc)
+        self._meta.pop(int(id), None)
+
+    def _raise_search(self, rc: int, requested: int):
+        if rc == VL_ERR_METRIC_MISMATCH:
+            raise MetricMismatch(SimilarityMetric(int(requested)), self.metric())
+        _raise(rc)
+
+    def search_batch(self, queries, k: int, metric: int, ef: int = 0):
+        """(ids [nq, k], scores [nq, k], n [nq]); ef = 0 is the reference's ef = min(k, len)."""
+        Q = _f64(queries)
+        if Q.ndim == 1:
+            Q = Q[None, :]
+        nq, qlen = Q.shape
+        kk = max(int(k), 1)
+        ids = np.zeros((nq, kk), dtype=np.uint64)
+        scores = np.zeros((nq, kk), dtype=np.float64)
+        n = np.zeros(max(nq, 1), dtype=np.uint64)
+        rc = self._L.vl_index_search_ef(self._h, _pf64(Q), nq, qlen, int(k), int(ef), int(metric), _pu64(ids),
+                                        _pf64(scores), _pu64(n))
+        self._raise_search(rc, metric)
+        return ids[:, : int(k)], scores[:, : int(k)], n[:nq]
+
+    def search_arrays(self, query, k: int, metric: int, ef: int = 0):
+        ids, scores, n = self.search_batch(_f64(query).ravel()[None, :], k, metric, ef)
+        m = int(n[0])
+        return ids[0, :m].copy(), scores[0, :m].copy()
+
+    def search(self, query, k: int, similarity_metric: int) -> List[SearchResult]:
+        q = _f64(query).ravel()
+        kk = max(int(k), 1)
+        ids = np.zeros(kk, dtype=np.uint64)
+        scores = np.zeros(kk, dtype=np.float64)
+        n = C.c_uint64(0)
+        rc = self._L.vl_index_search(self._h, _pf64(q), q.size, int(k), int(similarity_metric), _pu64(ids),
+                                     _pf64(scores), C.byref(n))
+        self._raise_search(rc, similarity_metric)
+        out = []
+        for i, s in zip(ids[: n.value].tolist(), scores[: n.value].tolist()):
+            text, md = self._meta.get(i, ("", None))
+            out.append(SearchResult(id=i, score=s, text=text, metadata=md))
+        return out
+
+    def len(self) -> int:
+        return int(self._L.vl_index_len(self._h))
+
+    __len__ = len
+
+    def is_empty(self) -> bool:
+        return bool(self._L.vl_index_is_empty(self._h))
+
+    def dimension(self) -> int:
+        return int(self._L.vl_index_dimension(self._h))
+
+    def get_vector(self, id: int) -> Optional[Vector]:
+        out = np.empty(self.dimension(), dtype=np.float64)
+        rc = self._L.vl_index_get_vector(self._h, int(id), _pf64(out))
+        if rc == VL_ERR_NOT_FOUND:
+            return None
+        _raise(rc)
+        text, md = self._meta.get(int(id), ("", None))
+        return Vector(id=int(id), values=out.tolist(), text=text, metadata=md)
+
+    def max_id(self) -> Optional[int]:
+        out = C.c_uint64(0)
+        rc = self._L.vl_index_max_id(self._h, C.byref(out))
+        if rc == VL_ERR_NOT_FOUND:
+            return None
+        _raise(rc)
+        return out.value

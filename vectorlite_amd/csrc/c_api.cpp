@@ -6,9 +6,14 @@
 #include <stdexcept>
 
 #include "flat_index.hpp"
+#include "hnsw_index.hpp"
 
+// enum VectorIndexWrapper { Flat(FlatIndex), HNSW(Box<HNSWIndex>) } (src/lib.rs:271-276): exactly one
+// of the two pointers is set; the vl_index_* entry points dispatch like the wrapper's impl
+// (src/lib.rs:278-327).
 struct vl_index {
     vl::GpuFlatIndex* flat;
+    vl::HnswIndex* hnsw;
 };
 
 namespace {
@@ -33,7 +38,7 @@ int guarded(F&& f)
 
 int wrap(vl::GpuFlatIndex* idx, vl_index** out)
 {
-    vl_index* h = new (std::nothrow) vl_index{idx};
+    vl_index* h = new (std::nothrow) vl_index{idx, nullptr};
     if (!h) {
         delete idx;
         return VL_ERR_OOM;
@@ -75,9 +80,46 @@ int vl_flat_from_rows(uint64_t dim, const uint64_t* ids, const double* values, u
     });
 }
 
+int vl_hnsw_create_ex(uint64_t dim, int metric, uint32_t m, uint32_t m0, uint32_t ef_construction, uint64_t seed,
+                      int device, vl_index** out)
+{
+    return guarded([&]() -> int {
+        if (!out) return VL_ERR_INVALID_ARG;
+        *out = nullptr;
+        vl::HnswParams p;
+        p.m = m;
+        p.m0 = m0;
+        p.ef_construction = ef_construction;
+        p.seed = seed;
+        vl::HnswIndex* idx = nullptr;
+        int rc = vl::HnswIndex::create(dim, metric, p, device, &idx);
+        if (rc != VL_OK) return rc;
+        vl_index* h = new (std::nothrow) vl_index{nullptr, idx};
+        if (!h) {
+            delete idx;
+            return VL_ERR_OOM;
+        }
+        *out = h;
+        return VL_OK;
+    });
+}
+
+int vl_hnsw_create(uint64_t dim, int metric, int device, vl_index** out)
+{
+    const vl::HnswParams d;  // default cargo profile: M = 16, M0 = 32 (src/index/hnsw.rs:95-109)
+    return vl_hnsw_create_ex(dim, metric, d.m, d.m0, d.ef_construction, d.seed, device, out);
+}
+
+#define VL_FLAT_ONLY(h)                                                         \
+    if (!(h) || !(h)->flat) {                                                   \
+        vl::set_last_error("this entry point needs a flat index handle");       \
+        return VL_ERR_INVALID_ARG;                                              \
+    }
+
 int vl_index_clone(const vl_index* h, vl_index** out)
 {
     return guarded([&]() -> int {
+        VL_FLAT_ONLY(h);
         if (!h || !out) return VL_ERR_INVALID_ARG;
         *out = nullptr;
         vl::GpuFlatIndex* c = nullptr;
@@ -92,6 +134,7 @@ void vl_index_destroy(vl_index* h)
     if (!h) return;
     try {
         delete h->flat;
+        delete h->hnsw;
     } catch (...) {
     }
     delete h;
@@ -99,26 +142,37 @@ void vl_index_destroy(vl_index* h)
 
 int vl_index_reserve(vl_index* h, uint64_t n_rows)
 {
-    return guarded([&]() -> int { return h ? h->flat->reserve(n_rows) : (int)VL_ERR_INVALID_ARG; });
+    return guarded([&]() -> int {
+        if (h && h->hnsw) return VL_OK;  // the graph grows on demand
+        VL_FLAT_ONLY(h);
+        return h->flat->reserve(n_rows);
+    });
 }
 
 int vl_index_add(vl_index* h, uint64_t id, const double* values, uint64_t len)
 {
-    return guarded([&]() -> int { return h ? h->flat->add(id, values, len) : (int)VL_ERR_INVALID_ARG; });
+    return guarded([&]() -> int {
+        if (!h) return VL_ERR_INVALID_ARG;
+        return h->hnsw ? h->hnsw->add(id, values, len) : h->flat->add(id, values, len);
+    });
 }
 
 int vl_index_add_bulk(vl_index* h, const uint64_t* ids, const double* values, uint64_t n, int validate,
                       int values_on_device)
 {
     return guarded([&]() -> int {
-        return h ? h->flat->add_bulk(ids, values, n, validate != 0, values_on_device != 0)
-                 : (int)VL_ERR_INVALID_ARG;
+        if (!h) return VL_ERR_INVALID_ARG;
+        if (h->hnsw) return h->hnsw->add_bulk(ids, values, n, values_on_device != 0);  // HNSW add always validates
+        return h->flat->add_bulk(ids, values, n, validate != 0, values_on_device != 0);
     });
 }
 
 int vl_index_delete(vl_index* h, uint64_t id)
 {
-    return guarded([&]() -> int { return h ? h->flat->remove(id) : (int)VL_ERR_INVALID_ARG; });
+    return guarded([&]() -> int {
+        if (!h) return VL_ERR_INVALID_ARG;
+        return h->hnsw ? h->hnsw->remove(id) : h->flat->remove(id);
+    });
 }
 
 int vl_index_search(const vl_index* h, const double* query, uint64_t q_len, uint64_t k, int metric,
@@ -126,6 +180,7 @@ int vl_index_search(const vl_index* h, const double* query, uint64_t q_len, uint
 {
     return guarded([&]() -> int {
         if (!h || !out_n) return VL_ERR_INVALID_ARG;
+        if (h->hnsw) return h->hnsw->search(query, q_len, k, metric, 0, out_ids, out_scores, out_n);
         if (!out_ids && k != 0 && h->flat->len() != 0) return VL_ERR_INVALID_ARG;
         return h->flat->search(query, q_len, k, metric, nullptr, out_ids, out_scores, out_n);
     });
@@ -135,7 +190,8 @@ int vl_index_search_positions(const vl_index* h, const double* query, uint64_t q
                               uint64_t* out_pos, uint64_t* out_ids, double* out_scores, uint64_t* out_n)
 {
     return guarded([&]() -> int {
-        if (!h || !out_n) return VL_ERR_INVALID_ARG;
+        VL_FLAT_ONLY(h);
+        if (!out_n) return VL_ERR_INVALID_ARG;
         return h->flat->search(query, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
     });
 }
@@ -145,6 +201,7 @@ int vl_index_search_batch(const vl_index* h, const double* queries, uint64_t nq,
 {
     return guarded([&]() -> int {
         if (!h || (!out_n && nq)) return VL_ERR_INVALID_ARG;
+        if (h->hnsw) return h->hnsw->search_batch(queries, nq, q_len, k, metric, 0, out_ids, out_scores, out_n);
         return h->flat->search_batch(queries, nq, q_len, k, metric, nullptr, out_ids, out_scores, out_n);
     });
 }
@@ -154,55 +211,77 @@ int vl_index_search_batch_positions(const vl_index* h, const double* queries, ui
                                     double* out_scores, uint64_t* out_n)
 {
     return guarded([&]() -> int {
-        if (!h || (!out_n && nq)) return VL_ERR_INVALID_ARG;
+        VL_FLAT_ONLY(h);
+        if (!out_n && nq) return VL_ERR_INVALID_ARG;
         return h->flat->search_batch(queries, nq, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
     });
 }
 
-uint64_t vl_index_len(const vl_index* h) { return h ? h->flat->len() : 0; }
-int vl_index_is_empty(const vl_index* h) { return h ? (h->flat->len() == 0) : 1; }
-uint64_t vl_index_dimension(const vl_index* h) { return h ? h->flat->dimension() : 0; }
+uint64_t vl_index_len(const vl_index* h) { return !h ? 0 : (h->hnsw ? h->hnsw->len() : h->flat->len()); }
+int vl_index_is_empty(const vl_index* h) { return vl_index_len(h) == 0; }
+uint64_t vl_index_dimension(const vl_index* h)
+{
+    return !h ? 0 : (h->hnsw ? h->hnsw->dimension() : h->flat->dimension());
+}
+
+// VectorIndexWrapper::index_type / ::metric (src/lib.rs:329-346): Flat -> (0, None), HNSW -> (1, Some(m)).
+int vl_index_type(const vl_index* h) { return (h && h->hnsw) ? 1 : 0; }
+int vl_index_metric(const vl_index* h, int* out_metric)
+{
+    if (!h || !out_metric) return VL_ERR_INVALID_ARG;
+    if (!h->hnsw) return VL_ERR_NOT_FOUND;  // None
+    *out_metric = h->hnsw->metric();
+    return VL_OK;
+}
+
+int vl_index_search_ef(const vl_index* h, const double* queries, uint64_t nq, uint64_t q_len, uint64_t k, uint32_t ef,
+                       int metric, uint64_t* out_ids, double* out_scores, uint64_t* out_n)
+{
+    return guarded([&]() -> int {
+        if (!h || !h->hnsw) {
+            vl::set_last_error("vl_index_search_ef needs an HNSW handle");
+            return VL_ERR_INVALID_ARG;
+        }
+        return h->hnsw->search_batch(queries, nq, q_len, k, metric, ef, out_ids, out_scores, out_n);
+    });
+}
 
 int vl_index_get_vector(const vl_index* h, uint64_t id, double* out_values)
 {
-    return guarded([&]() -> int { return h ? h->flat->get_vector(id, out_values) : (int)VL_ERR_INVALID_ARG; });
+    return guarded([&]() -> int {
+        if (!h || !out_values) return VL_ERR_INVALID_ARG;
+        return h->hnsw ? h->hnsw->get_vector(id, out_values) : h->flat->get_vector(id, out_values);
+    });
 }
 
 int vl_index_max_id(const vl_index* h, uint64_t* out_id)
 {
-    return guarded([&]() -> int { return h ? h->flat->max_id(out_id) : (int)VL_ERR_INVALID_ARG; });
+    return guarded([&]() -> int {
+        if (!h || !out_id) return VL_ERR_INVALID_ARG;
+        return h->hnsw ? h->hnsw->max_id(out_id) : h->flat->max_id(out_id);
+    });
 }
 
 int vl_index_export(const vl_index* h, uint64_t* out_ids, double* out_values)
 {
-    return guarded([&]() -> int { return h ? h->flat->export_rows(out_ids, out_values) : (int)VL_ERR_INVALID_ARG; });
+    return guarded([&]() -> int {
+        VL_FLAT_ONLY(h);
+        return h->flat->export_rows(out_ids, out_values);
+    });
 }
 
 int vl_index_hnsw_distances(const vl_index* h, const double* query, uint64_t q_len, int metric,
                             const uint64_t* positions, uint64_t m, uint64_t* out_dist)
 {
     return guarded([&]() -> int {
-        return h ? h->flat->hnsw_distances(query, q_len, metric, positions, m, out_dist) : (int)VL_ERR_INVALID_ARG;
+        VL_FLAT_ONLY(h);
+        return h->flat->hnsw_distances(query, q_len, metric, positions, m, out_dist);
     });
 }
 
 // convert_distance_to_similarity(d as f64 / 1000.0, metric): src/index/hnsw.rs:51-75, :478-479.
 // Four scalar operations on the k winners' u64 distances; no vector data is touched here.
-double vl_hnsw_score(uint64_t d_u64, int metric)
-{
-    const double distance = (double)d_u64 / 1000.0;
-    switch (metric) {
-    case VL_EUCLIDEAN:
-    case VL_MANHATTAN: return 1.0 / (1.0 + distance);
-    case VL_COSINE: return 1.0 - distance / 1000.0;
-    default: {
-        double v = (1000.0 - distance) / 1000.0;
-        if (v < 0.0) v = 0.0;
-        if (v > 1.0) v = 1.0;
-        return v;
-    }
-    }
-}
+double vl_hnsw_score(uint64_t d_u64, int metric) { return vl::hnsw_score(d_u64, metric); }
 
 const char* vl_last_error(void) { return vl::last_error(); }
 void vl_last_dim_mismatch(uint64_t* expected, uint64_t* actual) { vl::get_dim_mismatch(expected, actual); }
@@ -210,21 +289,21 @@ int vl_last_path(void) { return vl::last_path(); }
 
 int vl_index_force_path(vl_index* h, int path)
 {
-    if (!h || (path != 0 && path != VL_PATH_EXACT_SELECT && path != VL_PATH_EXACT_SORT)) return VL_ERR_INVALID_ARG;
+    if (!h || !h->flat || (path != 0 && path != VL_PATH_EXACT_SELECT && path != VL_PATH_EXACT_SORT)) return VL_ERR_INVALID_ARG;
     h->flat->force_path(path);
     return VL_OK;
 }
 
 int vl_index_profile_enable(vl_index* h, int enable)
 {
-    if (!h) return VL_ERR_INVALID_ARG;
+    if (!h || !h->flat) return VL_ERR_INVALID_ARG;
     h->flat->profile_enable(enable != 0);
     return VL_OK;
 }
 
 int vl_index_profile_read(vl_index* h, uint64_t* n_scan_launches, double* scan_ms_total, uint64_t* scan_bytes_total)
 {
-    if (!h) return VL_ERR_INVALID_ARG;
+    if (!h || !h->flat) return VL_ERR_INVALID_ARG;
     h->flat->profile_read(n_scan_launches, scan_ms_total, scan_bytes_total);
     return VL_OK;
 }

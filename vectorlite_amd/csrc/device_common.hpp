@@ -1,0 +1,151 @@
+// device_common.hpp -- device helpers shared by kernels.hip (flat scan) and hnsw.hip (graph walk).
+// Reference paths are relative to /root/reference.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+namespace vl {
+namespace dev {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+// Total order of candidates: higher key first, then lower storage position (the reference's
+// stable sort keeps insertion order on ties: src/index/flat.rs:116, src/client.rs:665-667).
+template <typename K>
+__device__ __forceinline__ bool better(K ka, uint32_t pa, K kb, uint32_t pb)
+{
+    return ka > kb || (ka == kb && pa < pb);
+}
+
+// ---- cross-lane moves without LDS traffic ------------------------------------------------------
+// lane i <- lane i-1 (lane 0 keeps its own value): one DPP wave_shr:1 move per dword.
+__device__ __forceinline__ int wave_shr1_dw(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xF, 0xF, false); }
+__device__ __forceinline__ float wave_shr1(float v) { return __int_as_float(wave_shr1_dw(__float_as_int(v))); }
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return (uint32_t)wave_shr1_dw((int)v); }
+__device__ __forceinline__ double wave_shr1(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = wave_shr1_dw((int)(b & 0xFFFFFFFFll)), hi = wave_shr1_dw((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ unsigned long long wave_shr1(unsigned long long b)
+{
+    const int lo = wave_shr1_dw((int)(b & 0xFFFFFFFFull)), hi = wave_shr1_dw((int)(b >> 32));
+    return ((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo;
+}
+// value of a wave-uniform lane (v_readlane_b32 into an SGPR)
+__device__ __forceinline__ unsigned long long read_lane(unsigned long long b, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFull), lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return ((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ float read_lane(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ uint32_t read_lane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ __forceinline__ double read_lane(double v, int lane)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Reference-order f64 arithmetic (this TU is built with -ffp-contract=off: `a += x * y` is one
+// rounded multiply followed by one rounded add, like rustc's output for src/lib.rs:425-572).
+// ---------------------------------------------------------------------------------------------
+template <int METRIC>
+struct Acc64 {
+    double a, b, c;
+    __device__ __forceinline__ void init()
+    {
+        // cosine folds from (0.0, 0.0, 0.0) (src/lib.rs:428); the `.sum::<f64>()` metrics fold from
+        // the float additive identity -0.0 (core::iter::Sum, rustc >= 1.83; crate edition 2024).
+        a = (METRIC == COSINE) ? 0.0 : -0.0;
+        b = 0.0;
+        c = 0.0;
+    }
+    __device__ __forceinline__ void step(double x, double y)
+    {
+        if (METRIC == COSINE) {
+            a += x * y;
+            b += x * x;
+            c += y * y;
+        } else if (METRIC == EUCLIDEAN) {
+            const double d = x - y;
+            a += d * d;
+        } else if (METRIC == MANHATTAN) {
+            a += fabs(x - y);
+        } else {
+            a += x * y;
+        }
+    }
+    // SimilarityMetric::calculate's return value
+    __device__ __forceinline__ double score() const
+    {
+        if (METRIC == COSINE) {
+            const double na = sqrt(b), nb = sqrt(c);
+            if (na == 0.0 || nb == 0.0) return 0.0;
+            return a / (na * nb);
+        }
+        if (METRIC == EUCLIDEAN) return 1.0 / (1.0 + sqrt(a));
+        if (METRIC == MANHATTAN) return 1.0 / (1.0 + a);
+        return a;
+    }
+};
+
+// Rust `f64 as u64`: truncation toward zero, saturating, NaN -> 0.
+__device__ __forceinline__ unsigned long long rust_as_u64(double v)
+{
+    if (!(v > 0.0)) return 0ull;
+    if (v >= 18446744073709551616.0) return ~0ull;
+    return (unsigned long long)v;
+}
+
+// impl Metric<Vec<f64>>::distance (src/index/hnsw.rs:113-174), split in two steps:
+// hnsw_scaled() is the f64 value the reference hands to `as u64`; hnsw_quantise() applies the cast.
+template <int METRIC>
+__device__ __forceinline__ double hnsw_scaled(const Acc64<METRIC>& A)
+{
+    if (METRIC == EUCLIDEAN) return sqrt(A.a) * 1000.0;
+    if (METRIC == COSINE) {
+        const double na = sqrt(A.b), nb = sqrt(A.c);
+        if (na == 0.0 || nb == 0.0) return 1000.0;  // `return 1000` (:139-141)
+        const double cosine_sim = A.a / (na * nb);
+        return (1.0 - cosine_sim) * 1000.0;
+    }
+    if (METRIC == MANHATTAN) return A.a * 1000.0;
+    double d = A.a;  // f64::clamp(-1000, 1000): NaN stays NaN
+    if (d < -1000.0) d = -1000.0;
+    if (d > 1000.0) d = 1000.0;
+    return 1000.0 - d;
+}
+template <int METRIC>
+__device__ __forceinline__ unsigned long long hnsw_quantise(const Acc64<METRIC>& A)
+{
+    return rust_as_u64(hnsw_scaled<METRIC>(A));
+}
+// Walk key: a u64 whose unsigned order refines the reference's u64 distance order (it is the f64
+// bit pattern of the scaled distance, clamped like `as u64` clamps: negative / NaN -> 0).  Two
+// nodes the reference's truncation would tie are still told apart, which keeps a greedy walk from
+// stalling on plateaus; rust_as_u64(key_to_scaled(key)) is exactly the reference's distance.
+__device__ __forceinline__ unsigned long long walk_key(double scaled)
+{
+    if (!(scaled > 0.0)) return 0ull;
+    return (unsigned long long)__double_as_longlong(scaled);
+}
+__device__ __forceinline__ unsigned long long walk_key_to_u64(unsigned long long key)
+{
+    return rust_as_u64(__longlong_as_double((long long)key));
+}
+
+
+}  // namespace dev
+}  // namespace vl

@@ -103,6 +103,10 @@ public:
     int hnsw_distances(const double* query, uint64_t q_len, int metric, const uint64_t* positions, uint64_t m,
                        uint64_t* out) const;
 
+    // storage access for the HNSW graph layered on top of this row store (hnsw_index.cpp)
+    const double* device_master() const { return d_master_; }
+    uint64_t capacity() const { return cap_; }
+
     void force_path(int p) { force_path_.store(p); }
     void profile_enable(bool on);
     void profile_read(uint64_t* n, double* ms, uint64_t* bytes);

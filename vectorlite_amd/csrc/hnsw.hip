@@ -1,0 +1,526 @@
+// hnsw.hip -- GPU graph walk and batched graph build behind the reference's HNSWIndex.
+// See hnsw.hpp for what is the reference's (the u64 distance callbacks, reproduced bit for bit)
+// and what is our own (the walk: parity with crate hnsw 0.11.0 is unpinned).
+//
+// One WAVE per query / per inserted node:
+//   * the query sits in LDS as f64; a hop loads the <= 32 neighbour ids of the expanded node with
+//     one coalesced load, filters them through a per-wave visited-stamp array in HBM, and each
+//     surviving lane walks ITS neighbour's f64 row in index order (separate multiply and add) to
+//     produce the reference's u64 distance -- the per-hop distance kernel of north_star;
+//   * the beam (result list + frontier in one) is a sorted list held one or two entries per lane,
+//     updated with ballot / DPP shifts like the flat scan's top-k list.
+#include "hnsw.hpp"
+
+#include <type_traits>
+
+#include "device_common.hpp"
+
+namespace vl {
+using namespace dev;
+namespace {
+
+constexpr uint32_t EXPANDED = 0x80000000u;  // flag bit in the node word (node ids < 2^31)
+
+// Sorted beam: ascending by (dist, node); capacity 64*S, logical width `ef` <= 64*S.
+template <int S>
+struct BeamList {
+    unsigned long long d[S];
+    uint32_t v[S];
+
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            d[s] = ~0ull;
+            v[s] = HNSW_NONE;  // carries the EXPANDED bit: never picked for expansion
+        }
+    }
+    __device__ __forceinline__ int rank_of(unsigned long long dist, uint32_t node) const
+    {
+        int c = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            c += __popcll(__ballot(d[s] < dist || (d[s] == dist && (v[s] & ~EXPANDED) < node)));
+        return c;
+    }
+    __device__ __forceinline__ void insert(unsigned long long dist, uint32_t node, int ef)
+    {
+        const int idx = rank_of(dist, node);
+        if (idx >= ef) return;  // wave-uniform
+        const int lane = lane_id();
+#pragma unroll
+        for (int s = S - 1; s >= 0; --s) {  // top slot first: it reads the slot below before that moves
+            const int j = s * 64 + lane;
+            unsigned long long pd = wave_shr1(d[s]);
+            uint32_t pv = wave_shr1(v[s]);
+            if (s > 0) {
+                const unsigned long long cd = read_lane(d[s > 0 ? s - 1 : 0], 63);
+                const uint32_t cv = read_lane(v[s > 0 ? s - 1 : 0], 63);
+                if (lane == 0) {
+                    pd = cd;
+                    pv = cv;
+                }
+            }
+            if (j == idx) {
+                d[s] = dist;
+                v[s] = node;
+            } else if (j > idx) {
+                d[s] = pd;
+                v[s] = pv;
+            }
+            if (j >= ef) {
+                d[s] = ~0ull;
+                v[s] = HNSW_NONE;
+            }
+        }
+    }
+    __device__ __forceinline__ void get(int idx, unsigned long long& dist, uint32_t& node) const
+    {
+        if (S > 1 && idx >= 64) {
+            dist = read_lane(d[S - 1], idx - 64);
+            node = read_lane(v[S - 1], idx - 64);
+        } else {
+            dist = read_lane(d[0], idx);
+            node = read_lane(v[0], idx);
+        }
+    }
+    __device__ __forceinline__ int next_unexpanded() const
+    {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const unsigned long long m = __ballot((v[s] & EXPANDED) == 0u);
+            if (m) return s * 64 + __ffsll((long long)m) - 1;
+        }
+        return -1;
+    }
+    __device__ __forceinline__ void mark_expanded(int idx)
+    {
+        const int lane = lane_id();
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if (s * 64 + lane == idx) v[s] |= EXPANDED;
+    }
+    // every real entry becomes an unexpanded entry point again (next layer)
+    __device__ __forceinline__ void reopen()
+    {
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if (v[s] != HNSW_NONE) v[s] &= ~EXPANDED;
+    }
+    __device__ __forceinline__ void truncate(int ef)
+    {
+        const int lane = lane_id();
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if (s * 64 + lane >= ef) {
+                d[s] = ~0ull;
+                v[s] = HNSW_NONE;
+            }
+    }
+};
+
+// Metric::distance(query, row) (src/index/hnsw.rs:113-174) as a walk key (see walk_key): one lane
+// walks one row in the reference's f64 operation order.
+template <int METRIC>
+__device__ __forceinline__ unsigned long long row_distance(const double* __restrict__ row, const double* q,
+                                                           uint32_t dim)
+{
+    Acc64<METRIC> A;
+    A.init();
+    uint32_t i = 0;
+    if ((dim & 1u) == 0u) {  // rows are 16-byte aligned: two values per load, 8 loads in flight
+        const double2* r2 = reinterpret_cast<const double2*>(row);
+        for (; i + 16 <= dim; i += 16) {
+            double2 x[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) x[t] = r2[i / 2 + t];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                A.step(x[t].x, q[i + 2 * t]);
+                A.step(x[t].y, q[i + 2 * t + 1]);
+            }
+        }
+    }
+    for (; i < dim; ++i) A.step(row[i], q[i]);
+    return walk_key(hnsw_scaled<METRIC>(A));
+}
+
+struct LayerView {
+    const uint32_t* nbr;
+    uint32_t cnt;
+};
+
+__device__ __forceinline__ LayerView layer_of(const HnswGraphView& g, uint32_t node, int layer)
+{
+    LayerView lv;
+    if (layer == 0) {
+        lv.nbr = g.nbr0 + (size_t)node * g.m0;
+        lv.cnt = g.cnt0[node];
+    } else {
+        const uint32_t slot = g.upper_off[node] + (uint32_t)(layer - 1);
+        lv.nbr = g.nbrU + (size_t)slot * g.m;
+        lv.cnt = g.cntU[slot];
+    }
+    return lv;
+}
+
+// Beam search of width ef on one layer.  Precondition: L holds the entry points (unexpanded) and
+// their stamps are set.
+template <int METRIC, int S>
+__device__ __forceinline__ void beam_layer(const HnswGraphView& g, const double* q, int layer, uint32_t* stamps,
+                                           uint32_t epoch, BeamList<S>& L, int ef)
+{
+    const int lane = lane_id();
+    for (;;) {
+        const int idx = L.next_unexpanded();
+        if (idx < 0) break;
+        unsigned long long dc;
+        uint32_t c;
+        L.get(idx, dc, c);
+        L.mark_expanded(idx);
+        const LayerView lv = layer_of(g, c, layer);
+        uint32_t e = (uint32_t)lane < lv.cnt ? lv.nbr[lane] : HNSW_NONE;
+        bool act = e != HNSW_NONE;
+        if (act) {
+            if (stamps[e] == epoch) act = false;
+            else stamps[e] = epoch;
+        }
+        unsigned long long de = ~0ull;
+        if (act) de = row_distance<METRIC>(g.master + (size_t)e * g.dim, q, g.dim);
+        // the current worst only shrinks while we insert: a stale value lets a few extra lanes through,
+        // insert() re-checks the rank
+        unsigned long long w;
+        uint32_t wn;
+        L.get(ef - 1, w, wn);
+        unsigned long long m = __ballot(act && (wn == HNSW_NONE || de <= w));
+        while (m) {
+            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+            m &= m - 1;
+            L.insert(read_lane(de, src), read_lane(e, src), ef);
+        }
+    }
+}
+
+// Move to the next layer: keep the entries as entry points, fresh visited epoch.
+template <int S>
+__device__ __forceinline__ void next_layer(BeamList<S>& L, uint32_t* stamps, uint32_t& epoch)
+{
+    epoch += 1;
+    L.reopen();
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+        if (L.v[s] != HNSW_NONE) stamps[L.v[s] & ~EXPANDED] = epoch;
+}
+
+template <int METRIC, int S>
+__global__ __launch_bounds__(256) void k_hnsw_search(HnswGraphView g, const double* __restrict__ queries, uint32_t nq,
+                                                     uint32_t ef, uint32_t entry, int max_level,
+                                                     HnswHit* __restrict__ out)
+{
+    extern __shared__ double q_lds[];  // [4][dim]
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const uint32_t slot = blockIdx.x * 4 + wave;
+    if (slot >= g.n_slots) return;
+    double* q = q_lds + (size_t)wave * g.dim;
+    uint32_t* stamps = g.stamps + (size_t)slot * g.cap;
+    uint32_t epoch = g.epochs[slot];
+
+    for (uint32_t qi = slot; qi < nq; qi += gridDim.x * 4) {
+        for (uint32_t i = lane; i < g.dim; i += 64) q[i] = queries[(size_t)qi * g.dim + i];
+        __builtin_amdgcn_wave_barrier();
+        BeamList<S> L;
+        L.init();
+        epoch += 1;
+        {
+            unsigned long long d0 = 0;
+            if (lane == 0) d0 = row_distance<METRIC>(g.master + (size_t)entry * g.dim, q, g.dim);
+            d0 = read_lane(d0, 0);
+            L.insert(d0, entry, 1);
+            if (lane == 0) stamps[entry] = epoch;
+        }
+        for (int layer = max_level; layer >= 1; --layer) {
+            beam_layer<METRIC, S>(g, q, layer, stamps, epoch, L, 1);
+            next_layer(L, stamps, epoch);
+        }
+        beam_layer<METRIC, S>(g, q, 0, stamps, epoch, L, (int)ef);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint32_t j = s * 64 + lane;
+            if (j < ef) {
+                HnswHit h;
+                h.dist = walk_key_to_u64(L.d[s]);  // the reference's u64 distance
+                h.node = L.v[s] == HNSW_NONE ? HNSW_NONE : (L.v[s] & ~EXPANDED);
+                h.pad = 0;
+                out[(size_t)qi * ef + j] = h;
+            }
+        }
+    }
+    if (lane == 0) g.epochs[slot] = epoch;
+}
+
+// Build phase A: node p = first + i searches the graph of the nodes < first and fills its own lists.
+template <int METRIC, int S>
+__global__ __launch_bounds__(256) void k_hnsw_insert_search(HnswGraphView g, uint32_t first, uint32_t n, uint32_t efc,
+                                                            uint32_t entry, int max_level, uint32_t flags)
+{
+    extern __shared__ double q_lds[];  // [4][2][dim]: the node's own row, then a candidate row
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const uint32_t slot = blockIdx.x * 4 + wave;
+    if (slot >= g.n_slots) return;
+    double* q = q_lds + (size_t)wave * 2 * g.dim;
+    double* cand = q + g.dim;
+    uint32_t* stamps = g.stamps + (size_t)slot * g.cap;
+    uint32_t epoch = g.epochs[slot];
+
+    for (uint32_t i = slot; i < n; i += gridDim.x * 4) {
+        const uint32_t p = first + i;
+        const int lp = g.level[p];
+        for (uint32_t c = lane; c < g.dim; c += 64) q[c] = g.master[(size_t)p * g.dim + c];
+        __builtin_amdgcn_wave_barrier();
+        BeamList<S> L;
+        L.init();
+        epoch += 1;
+        {
+            unsigned long long d0 = 0;
+            if (lane == 0) d0 = row_distance<METRIC>(g.master + (size_t)entry * g.dim, q, g.dim);
+            d0 = read_lane(d0, 0);
+            L.insert(d0, entry, 1);
+            if (lane == 0) stamps[entry] = epoch;
+        }
+        for (int layer = max_level; layer > lp; --layer) {  // greedy descent above the node's own level
+            beam_layer<METRIC, S>(g, q, layer, stamps, epoch, L, 1);
+            next_layer(L, stamps, epoch);
+        }
+        for (int layer = lp < max_level ? lp : max_level; layer >= 0; --layer) {
+            beam_layer<METRIC, S>(g, q, layer, stamps, epoch, L, (int)efc);
+            // neighbour selection (the HNSW diversity heuristic): walk the beam from the closest
+            // candidate outwards and keep a candidate only if it is closer to p than to every
+            // neighbour kept so far -- this is what gives the graph its long edges.  Lane j holds
+            // kept neighbour j and checks candidates against it in parallel (one row walk per lane).
+            const uint32_t cap = layer == 0 ? g.m0 : g.m;
+            uint32_t* nb;
+            unsigned long long* nd;
+            uint32_t* cnt;
+            if (layer == 0) {
+                nb = g.nbr0 + (size_t)p * g.m0;
+                nd = g.dist0 + (size_t)p * g.m0;
+                cnt = g.cnt0 + p;
+            } else {
+                const uint32_t us = g.upper_off[p] + (uint32_t)(layer - 1);
+                nb = g.nbrU + (size_t)us * g.m;
+                nd = g.distU + (size_t)us * g.m;
+                cnt = g.cntU + us;
+            }
+            int total = 0;
+#pragma unroll
+            for (int s = 0; s < S; ++s) total += __popcll(__ballot(L.v[s] != HNSW_NONE));
+            uint32_t selv = HNSW_NONE;
+            unsigned long long seld = 0;
+            uint32_t nsel = 0;
+            unsigned long long kept_lo = 0, kept_hi = 0;  // which beam entries were kept
+            for (int ci = 0; ci < total && nsel < cap; ++ci) {
+                unsigned long long dc;
+                uint32_t cv;
+                L.get(ci, dc, cv);
+                cv &= ~EXPANDED;
+                bool bad = false;
+                if (nsel > 0 && (flags & 1u)) {
+                    for (uint32_t c = lane; c < g.dim; c += 64) cand[c] = g.master[(size_t)cv * g.dim + c];
+                    __builtin_amdgcn_wave_barrier();
+                    if ((uint32_t)lane < nsel)
+                        bad = row_distance<METRIC>(g.master + (size_t)selv * g.dim, cand, g.dim) < dc;
+                }
+                if (__ballot(bad) == 0ull) {
+                    if ((uint32_t)lane == nsel) {
+                        selv = cv;
+                        seld = dc;
+                    }
+                    ++nsel;
+                    if (ci < 64) kept_lo |= 1ull << ci;
+                    else kept_hi |= 1ull << (ci - 64);
+                }
+            }
+            if (flags & 2u) {  // back-fill with the closest pruned candidates: keeps the degree at cap
+                for (int ci = 0; ci < total && nsel < cap; ++ci) {
+                    const bool kept = ci < 64 ? ((kept_lo >> ci) & 1ull) : ((kept_hi >> (ci - 64)) & 1ull);
+                    if (kept) continue;
+                    unsigned long long dc;
+                    uint32_t cv;
+                    L.get(ci, dc, cv);
+                    if ((uint32_t)lane == nsel) {
+                        selv = cv & ~EXPANDED;
+                        seld = dc;
+                    }
+                    ++nsel;
+                }
+            }
+            if ((uint32_t)lane < nsel) {
+                nb[lane] = selv;
+                nd[lane] = seld;
+            }
+            if (lane == 0) *cnt = nsel;
+            if (layer > 0) next_layer(L, stamps, epoch);
+        }
+    }
+    if (lane == 0) g.epochs[slot] = epoch;
+}
+
+// Build phase B: add p to the lists of the neighbours it chose (replace the farthest if full and
+// p is closer).  One wave per new node; a neighbour's list is updated under its spin lock with
+// agent-scope fences (other XCDs' L2s are not coherent: MI355X_MICROARCH.md).
+__global__ __launch_bounds__(256) void k_hnsw_insert_link(HnswGraphView g, uint32_t first, uint32_t n, int max_level)
+{
+    const int lane = lane_id();
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (uint32_t i = w; i < n; i += gridDim.x * 4) {
+        const uint32_t p = first + i;
+        const int lp = g.level[p];
+        const int top = lp < max_level ? lp : max_level;
+        for (int layer = 0; layer <= top; ++layer) {
+            const uint32_t cap = layer == 0 ? g.m0 : g.m;
+            const uint32_t* pnb;
+            const unsigned long long* pnd;
+            uint32_t pcnt;
+            if (layer == 0) {
+                pnb = g.nbr0 + (size_t)p * g.m0;
+                pnd = g.dist0 + (size_t)p * g.m0;
+                pcnt = g.cnt0[p];
+            } else {
+                const uint32_t us = g.upper_off[p] + (uint32_t)(layer - 1);
+                pnb = g.nbrU + (size_t)us * g.m;
+                pnd = g.distU + (size_t)us * g.m;
+                pcnt = g.cntU[us];
+            }
+            for (uint32_t t = 0; t < pcnt; ++t) {
+                const uint32_t qn = pnb[t];
+                const unsigned long long d = pnd[t];
+                if (lane == 0) {
+                    while (atomicCAS(&g.lock[qn], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(4);
+                }
+                __threadfence();  // acquire: see the previous holder's list
+                uint32_t* qb;
+                unsigned long long* qd;
+                uint32_t* qc;
+                if (layer == 0) {
+                    qb = g.nbr0 + (size_t)qn * g.m0;
+                    qd = g.dist0 + (size_t)qn * g.m0;
+                    qc = g.cnt0 + qn;
+                } else {
+                    const uint32_t us = g.upper_off[qn] + (uint32_t)(layer - 1);
+                    qb = g.nbrU + (size_t)us * g.m;
+                    qd = g.distU + (size_t)us * g.m;
+                    qc = g.cntU + us;
+                }
+                const uint32_t cq = __hip_atomic_load(qc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cq < cap) {
+                    if (lane == 0) {
+                        qb[cq] = p;
+                        qd[cq] = d;
+                        __hip_atomic_store(qc, cq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else {
+                    // farthest entry by (dist, node)
+                    unsigned long long md = (uint32_t)lane < cap ? __hip_atomic_load(qd + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                    uint32_t mv = (uint32_t)lane < cap ? __hip_atomic_load(qb + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    int ml = lane;
+                    if ((uint32_t)lane >= cap) ml = -1;
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) {
+                        const unsigned long long od = __shfl_xor(md, o);
+                        const uint32_t ov = __shfl_xor(mv, o);
+                        const int ol = __shfl_xor(ml, o);
+                        const bool take = ol >= 0 && (ml < 0 || od > md || (od == md && ov > mv));
+                        if (take) {
+                            md = od;
+                            mv = ov;
+                            ml = ol;
+                        }
+                    }
+                    if (d < md || (d == md && p < mv)) {
+                        if (lane == ml) {
+                            qb[lane] = p;
+                            qd[lane] = d;
+                        }
+                    }
+                }
+                __threadfence();  // release: the list is complete before the lock opens
+                if (lane == 0) atomicExch(&g.lock[qn], 0u);
+            }
+        }
+    }
+}
+
+template <typename F>
+hipError_t dispatch_metric(int metric, F&& f)
+{
+    switch (metric) {
+    case COSINE: return f(std::integral_constant<int, COSINE>{});
+    case EUCLIDEAN: return f(std::integral_constant<int, EUCLIDEAN>{});
+    case MANHATTAN: return f(std::integral_constant<int, MANHATTAN>{});
+    case DOT: return f(std::integral_constant<int, DOT>{});
+    default: return hipErrorInvalidValue;
+    }
+}
+
+int grid_for(const HnswGraphView& g, uint32_t work)
+{
+    uint32_t waves = work < g.n_slots ? work : g.n_slots;
+    uint32_t blocks = (waves + 3) / 4;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+}  // namespace
+
+hipError_t launch_hnsw_search(hipStream_t s, int metric, const HnswGraphView& g, const double* queries, uint32_t nq,
+                              uint32_t ef, uint32_t entry, int max_level, HnswHit* out)
+{
+    if (nq == 0) return hipSuccess;
+    if (ef == 0 || ef > (uint32_t)HNSW_MAX_EF || g.m0 > 64 || g.m > 64) return hipErrorInvalidValue;
+    const size_t lds = (size_t)4 * g.dim * sizeof(double);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    const int grid = grid_for(g, nq);
+    return dispatch_metric(metric, [&](auto M) -> hipError_t {
+        constexpr int MM = decltype(M)::value;
+        if (ef <= 64)
+            hipLaunchKernelGGL((k_hnsw_search<MM, 1>), dim3(grid), dim3(256), lds, s, g, queries, nq, ef, entry,
+                               max_level, out);
+        else
+            hipLaunchKernelGGL((k_hnsw_search<MM, 2>), dim3(grid), dim3(256), lds, s, g, queries, nq, ef, entry,
+                               max_level, out);
+        return hipGetLastError();
+    });
+}
+
+hipError_t launch_hnsw_insert_search(hipStream_t s, int metric, const HnswGraphView& g, uint32_t first, uint32_t n,
+                                     uint32_t ef_construction, uint32_t entry, int max_level, uint32_t flags)
+{
+    if (n == 0) return hipSuccess;
+    if (ef_construction == 0 || ef_construction > (uint32_t)HNSW_MAX_EF || g.m0 > 64 || g.m > 64)
+        return hipErrorInvalidValue;
+    const size_t lds = (size_t)8 * g.dim * sizeof(double);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    const int grid = grid_for(g, n);
+    return dispatch_metric(metric, [&](auto M) -> hipError_t {
+        constexpr int MM = decltype(M)::value;
+        if (ef_construction <= 64)
+            hipLaunchKernelGGL((k_hnsw_insert_search<MM, 1>), dim3(grid), dim3(256), lds, s, g, first, n,
+                               ef_construction, entry, max_level, flags);
+        else
+            hipLaunchKernelGGL((k_hnsw_insert_search<MM, 2>), dim3(grid), dim3(256), lds, s, g, first, n,
+                               ef_construction, entry, max_level, flags);
+        return hipGetLastError();
+    });
+}
+
+hipError_t launch_hnsw_insert_link(hipStream_t s, const HnswGraphView& g, uint32_t first, uint32_t n, int max_level)
+{
+    if (n == 0) return hipSuccess;
+    const uint32_t blocks = (n + 3) / 4;
+    const int grid = (int)(blocks < 4096 ? blocks : 4096);
+    hipLaunchKernelGGL(k_hnsw_insert_link, dim3(grid), dim3(256), 0, s, g, first, n, max_level);
+    return hipGetLastError();
+}
+
+}  // namespace vl

@@ -1,0 +1,62 @@
+// hnsw.hpp -- device graph walk behind the reference's HNSWIndex (src/index/hnsw.rs).
+//
+// What the reference owns and this file reproduces exactly: the four `Metric::distance`
+// callbacks -> u64 (src/index/hnsw.rs:113-174), evaluated per hop on the GPU in the reference's
+// f64 operation order (device_common.hpp: Acc64 + hnsw_quantise).
+// What the reference delegates to crate `hnsw 0.11.0` (source not vendored, Cargo.lock:1111-1123):
+// the graph build and walk.  This is OUR OWN traversal (standard HNSW: greedy descent through the
+// upper layers, beam search of width ef on layer 0; M = 16, M0 = 32 like src/index/hnsw.rs:95-109).
+// Its parity with the crate is UNPINNED; it is judged by recall against exact search.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vl {
+
+constexpr uint32_t HNSW_NONE = 0xFFFFFFFFu;
+constexpr int HNSW_MAX_EF = 128;       // beam width ceiling (two list entries per lane)
+constexpr int HNSW_MAX_LEVEL = 15;
+
+struct HnswGraphView {
+    const double* master;  // [cap, dim] f64 rows (node index = storage position)
+    uint32_t dim;
+    uint32_t m, m0;        // max neighbours per node: upper layers / layer 0
+    // layer 0
+    uint32_t* nbr0;               // [cap, m0]
+    unsigned long long* dist0;    // [cap, m0] u64 distance of each edge (for replace-farthest)
+    uint32_t* cnt0;               // [cap]
+    // upper layers: node -> first slot; slot s + (layer-1) holds that layer's list
+    const uint8_t* level;         // [cap]
+    const uint32_t* upper_off;    // [cap]
+    uint32_t* nbrU;               // [slots, m]
+    unsigned long long* distU;    // [slots, m]
+    uint32_t* cntU;               // [slots]
+    uint32_t* lock;               // [cap] link-phase spin locks
+    // visited stamps: one u32 per node per concurrently running wave
+    uint32_t* stamps;             // [n_slots, cap]
+    uint32_t* epochs;             // [n_slots]
+    uint32_t n_slots;
+    uint64_t cap;
+};
+
+struct HnswHit {  // one neighbour returned by a walk
+    unsigned long long dist;  // Metric::distance(query, node) as the reference defines it
+    uint32_t node;
+    uint32_t pad;
+};
+
+// Query-time walk: nq queries (f64 [nq, dim]) -> out[nq][ef] sorted by (dist asc, node asc),
+// unused entries have node = HNSW_NONE.
+hipError_t launch_hnsw_search(hipStream_t s, int metric, const HnswGraphView& g, const double* queries, uint32_t nq,
+                              uint32_t ef, uint32_t entry, int max_level, HnswHit* out);
+
+// Build phase A: the rows [first, first+n) are new nodes; each walks the graph that holds the
+// nodes < first (entry/max_level describe it) with beam width ef_construction and writes its own
+// neighbour lists.  Phase B links them back into their neighbours' lists.
+// flags: bit 0 = diversity heuristic for neighbour selection, bit 1 = back-fill pruned candidates.
+hipError_t launch_hnsw_insert_search(hipStream_t s, int metric, const HnswGraphView& g, uint32_t first, uint32_t n,
+                                     uint32_t ef_construction, uint32_t entry, int max_level, uint32_t flags);
+hipError_t launch_hnsw_insert_link(hipStream_t s, const HnswGraphView& g, uint32_t first, uint32_t n, int max_level);
+
+}  // namespace vl

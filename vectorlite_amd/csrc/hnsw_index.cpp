@@ -1,0 +1,439 @@
+// hnsw_index.cpp -- host logic of the GPU HNSW index (see hnsw_index.hpp).
+//
+// Mirrors `impl VectorIndex for HNSWIndex` (reference src/index/hnsw.rs:363-496): argument meaning,
+// error texts, tombstone deletes, ef = min(k, len), score conversion, stable descending sort and
+// truncate(k).  Every distance is evaluated on the GPU (hnsw.hip); the host only keeps the id maps,
+// draws node levels and post-processes the <= ef (node, u64 distance) pairs a walk returns.
+#include "hnsw_index.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace vl {
+
+#define VL_HIP(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_));                   \
+            return (e_ == hipErrorOutOfMemory) ? (int)ERR_OOM : (int)ERR_DEVICE;                 \
+        }                                                                                        \
+    } while (0)
+#define VL_TRY(expr)               \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != OK) return rc_; \
+    } while (0)
+
+double hnsw_score(uint64_t d_u64, int metric)
+{
+    const double distance = (double)d_u64 / 1000.0;  // src/index/hnsw.rs:478
+    switch (metric) {                                 // src/index/hnsw.rs:51-75
+    case EUCLIDEAN:
+    case MANHATTAN: return 1.0 / (1.0 + distance);
+    case COSINE: return 1.0 - distance / 1000.0;
+    default: {
+        double v = (1000.0 - distance) / 1000.0;
+        if (v < 0.0) v = 0.0;
+        if (v > 1.0) v = 1.0;
+        return v;
+    }
+    }
+}
+
+namespace {
+constexpr uint32_t INSERT_BATCH_MAX = 4096;
+
+uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// level = floor(-ln(u) / ln(M)), u uniform in (0, 1]: the standard HNSW level law
+int draw_level(uint64_t seed, uint64_t node, uint32_t m)
+{
+    const uint64_t r = splitmix64(seed * 0x100000001B3ull + node);
+    const double u = ((double)(r >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+    int l = (int)std::floor(-std::log(u) / std::log((double)m));
+    if (l < 0) l = 0;
+    if (l > HNSW_MAX_LEVEL) l = HNSW_MAX_LEVEL;
+    return l;
+}
+
+template <typename T>
+int regrow(T** p, uint64_t old_count, uint64_t new_count, hipStream_t s, bool zero_new)
+{
+    T* np_ = nullptr;
+    VL_HIP(hipMalloc(reinterpret_cast<void**>(&np_), new_count * sizeof(T)));
+    if (zero_new) VL_HIP(hipMemsetAsync(np_, 0, new_count * sizeof(T), s));
+    if (*p && old_count) VL_HIP(hipMemcpyAsync(np_, *p, old_count * sizeof(T), hipMemcpyDeviceToDevice, s));
+    VL_HIP(hipStreamSynchronize(s));
+    if (*p) (void)hipFree(*p);
+    *p = np_;
+    return OK;
+}
+}  // namespace
+
+HnswIndex::HnswIndex(uint64_t dim, int metric, const HnswParams& p, int device)
+    : dim_(dim), metric_(metric), params_(p), device_(device)
+{
+}
+
+int HnswIndex::create(uint64_t dim, int metric, const HnswParams& p, int device, HnswIndex** out)
+{
+    if (!out) return ERR_INVALID_ARG;
+    *out = nullptr;
+    if (metric < 0 || metric > 3) return ERR_INVALID_ARG;
+    if (dim == 0) {  // HNSWIndex::new panics on dim 0 (src/index/hnsw.rs:217-219)
+        set_last_error("HNSW index dimension cannot be 0");
+        return ERR_INVALID_ARG;
+    }
+    if (p.m == 0 || p.m > 64 || p.m0 == 0 || p.m0 > 64 || p.ef_construction == 0 ||
+        p.ef_construction > (uint32_t)HNSW_MAX_EF || dim * 8 * sizeof(double) > 64 * 1024) {
+        set_last_error("HNSW parameters out of range (M, M0 <= 64; ef_construction <= 128; dim <= 1024)");
+        return ERR_INVALID_ARG;
+    }
+    std::unique_ptr<HnswIndex> h(new HnswIndex(dim, metric, p, device));
+    GpuFlatIndex* st = nullptr;
+    VL_TRY(GpuFlatIndex::create(dim, device, &st));
+    h->store_.reset(st);
+    VL_HIP(hipSetDevice(device));
+    VL_HIP(hipStreamCreateWithFlags(&h->stream_, hipStreamNonBlocking));
+    *out = h.release();
+    return OK;
+}
+
+HnswIndex::~HnswIndex()
+{
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    void* dev[] = {d_nbr0_, d_dist0_, d_cnt0_, d_level_, d_upper_off_, d_nbrU_, d_distU_, d_cntU_,
+                   d_lock_, d_stamps_, d_epochs_, d_q_, d_hits_};
+    for (void* p : dev)
+        if (p) (void)hipFree(p);
+    if (h_q_) (void)hipHostFree(h_q_);
+    if (h_hits_) (void)hipHostFree(h_hits_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+uint64_t HnswIndex::len() const
+{
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    return live_count_;
+}
+
+HnswGraphView HnswIndex::view() const
+{
+    HnswGraphView g;
+    g.master = store_->device_master();
+    g.dim = (uint32_t)dim_;
+    g.m = params_.m;
+    g.m0 = params_.m0;
+    g.nbr0 = d_nbr0_;
+    g.dist0 = d_dist0_;
+    g.cnt0 = d_cnt0_;
+    g.level = d_level_;
+    g.upper_off = d_upper_off_;
+    g.nbrU = d_nbrU_;
+    g.distU = d_distU_;
+    g.cntU = d_cntU_;
+    g.lock = d_lock_;
+    g.stamps = d_stamps_;
+    g.epochs = d_epochs_;
+    g.n_slots = n_slots_;
+    g.cap = g_cap_;
+    return g;
+}
+
+int HnswIndex::ensure_graph(uint64_t nodes, uint64_t upper_slots)
+{
+    if (nodes > g_cap_) {
+        if (nodes >= 0x7FFFFFF0ull) {
+            set_last_error("HNSW node count exceeds 2^31");
+            return ERR_INVALID_ARG;
+        }
+        const uint64_t nc = std::max<uint64_t>({nodes, g_cap_ * 2, 1024});
+        VL_TRY(regrow(&d_nbr0_, g_cap_ * params_.m0, nc * params_.m0, stream_, false));
+        VL_TRY(regrow(&d_dist0_, g_cap_ * params_.m0, nc * params_.m0, stream_, false));
+        VL_TRY(regrow(&d_cnt0_, g_cap_, nc, stream_, true));
+        VL_TRY(regrow(&d_level_, g_cap_, nc, stream_, true));
+        VL_TRY(regrow(&d_upper_off_, g_cap_, nc, stream_, true));
+        VL_TRY(regrow(&d_lock_, g_cap_, nc, stream_, true));
+        // visited stamps: one u32 per node per concurrently walking wave, at most ~8 GB
+        uint64_t slots = (8ull << 30) / (nc * sizeof(uint32_t));
+        slots = std::min<uint64_t>(slots, 4096);
+        slots = std::max<uint64_t>(slots, 64) & ~3ull;
+        if (d_stamps_) (void)hipFree(d_stamps_);
+        if (d_epochs_) (void)hipFree(d_epochs_);
+        d_stamps_ = nullptr;
+        d_epochs_ = nullptr;
+        VL_HIP(hipMalloc(reinterpret_cast<void**>(&d_stamps_), slots * nc * sizeof(uint32_t)));
+        VL_HIP(hipMalloc(reinterpret_cast<void**>(&d_epochs_), slots * sizeof(uint32_t)));
+        VL_HIP(hipMemsetAsync(d_stamps_, 0, slots * nc * sizeof(uint32_t), stream_));
+        VL_HIP(hipMemsetAsync(d_epochs_, 0, slots * sizeof(uint32_t), stream_));
+        VL_HIP(hipStreamSynchronize(stream_));
+        n_slots_ = (uint32_t)slots;
+        g_cap_ = nc;
+    }
+    if (upper_slots > u_cap_) {
+        const uint64_t nc = std::max<uint64_t>({upper_slots, u_cap_ * 2, 256});
+        VL_TRY(regrow(&d_nbrU_, u_cap_ * params_.m, nc * params_.m, stream_, false));
+        VL_TRY(regrow(&d_distU_, u_cap_ * params_.m, nc * params_.m, stream_, false));
+        VL_TRY(regrow(&d_cntU_, u_cap_, nc, stream_, true));
+        u_cap_ = nc;
+    }
+    return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// add / delete (src/index/hnsw.rs:363-414)
+// ---------------------------------------------------------------------------------------------
+int HnswIndex::add(uint64_t id, const double* values, uint64_t len)
+{
+    if (len != dim_) {  // :364-366
+        set_dim_mismatch(dim_, len);
+        set_last_error("Vector dimension mismatch: expected " + std::to_string(dim_) + ", got " + std::to_string(len));
+        return ERR_DIM_MISMATCH;
+    }
+    return add_bulk(&id, values, 1, false);
+}
+
+int HnswIndex::add_bulk(const uint64_t* ids, const double* values, uint64_t n, bool values_on_device)
+{
+    if (n == 0) return OK;
+    if (!ids || !values) return ERR_INVALID_ARG;
+    std::unique_lock<std::shared_mutex> lk(mu_);
+    VL_HIP(hipSetDevice(device_));
+
+    // n sequential add() calls: stop at the first id that already exists (:368-370)
+    uint64_t n_take = n;
+    int rc_after = OK;
+    {
+        std::unordered_map<uint64_t, uint32_t> seen;
+        for (uint64_t i = 0; i < n; ++i) {
+            if (id_to_node_.count(ids[i]) || seen.count(ids[i])) {
+                n_take = i;
+                rc_after = ERR_DUP_ID;
+                set_last_error("Vector ID " + std::to_string(ids[i]) + " already exists");
+                break;
+            }
+            seen.emplace(ids[i], 0);
+        }
+    }
+    if (n_take == 0) return rc_after;
+
+    const uint64_t first = n_nodes_;
+    if (store_->len() != first) {
+        set_last_error("row store and graph out of step");
+        return ERR_DEVICE;
+    }
+    VL_TRY(store_->add_bulk(ids, values, n_take, /*validate=*/false, values_on_device));
+
+    // node levels and upper-layer slots
+    std::vector<uint8_t> lv(n_take);
+    std::vector<uint32_t> off(n_take);
+    uint64_t upper = n_upper_;
+    for (uint64_t i = 0; i < n_take; ++i) {
+        const int l = draw_level(params_.seed, first + i, params_.m);
+        lv[i] = (uint8_t)l;
+        off[i] = (uint32_t)upper;
+        upper += (uint64_t)l;
+    }
+    VL_TRY(ensure_graph(first + n_take, upper));
+    VL_HIP(hipMemcpyAsync(d_level_ + first, lv.data(), n_take, hipMemcpyHostToDevice, stream_));
+    VL_HIP(hipMemcpyAsync(d_upper_off_ + first, off.data(), n_take * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+    VL_HIP(hipStreamSynchronize(stream_));  // lv/off are stack-owned
+    level_.insert(level_.end(), lv.begin(), lv.end());
+    upper_off_.insert(upper_off_.end(), off.begin(), off.end());
+    n_upper_ = upper;
+
+    // batched insertion: every batch walks the graph of all earlier nodes (phase A), then links
+    // itself in (phase B).  Batches stay small against the graph they search (<= 1/8 of it).
+    {
+        std::lock_guard<std::mutex> sg(search_mu_);
+        uint64_t pos = first;
+        const uint64_t end = first + n_take;
+        const char* sf = getenv("VL_HNSW_SELECT");  // tuning: 0 closest-M, 1 heuristic, 3 heuristic + back-fill
+        const uint32_t select_flags = sf && *sf ? (uint32_t)atoi(sf) : 3u;
+        const char* bd = getenv("VL_HNSW_BATCH_DIV");
+        const uint64_t batch_div = bd && *bd ? (uint64_t)std::max(1, atoi(bd)) : 8;
+        if (entry_ == HNSW_NONE) {
+            entry_ = (uint32_t)pos;
+            max_level_ = level_[pos];
+            ++pos;
+        }
+        while (pos < end) {
+            uint64_t b = std::max<uint64_t>(1, pos / batch_div);
+            b = std::min<uint64_t>({b, (uint64_t)INSERT_BATCH_MAX, end - pos});
+            const HnswGraphView g = view();
+            VL_HIP(launch_hnsw_insert_search(stream_, metric_, g, (uint32_t)pos, (uint32_t)b, params_.ef_construction,
+                                             entry_, max_level_, select_flags));
+            VL_HIP(launch_hnsw_insert_link(stream_, g, (uint32_t)pos, (uint32_t)b, max_level_));
+            for (uint64_t i = pos; i < pos + b; ++i) {
+                if ((int)level_[i] > max_level_) {  // a taller node becomes the entry point
+                    max_level_ = level_[i];
+                    entry_ = (uint32_t)i;
+                }
+            }
+            pos += b;
+        }
+        VL_HIP(hipStreamSynchronize(stream_));
+    }
+
+    node_id_.insert(node_id_.end(), ids, ids + n_take);
+    live_.insert(live_.end(), n_take, 1);
+    for (uint64_t i = 0; i < n_take; ++i) id_to_node_[ids[i]] = (uint32_t)(first + i);
+    n_nodes_ += n_take;
+    live_count_ += n_take;
+    return rc_after;
+}
+
+int HnswIndex::remove(uint64_t id)
+{
+    std::unique_lock<std::shared_mutex> lk(mu_);
+    auto it = id_to_node_.find(id);
+    if (it == id_to_node_.end()) {  // :401-403
+        set_last_error("Vector ID " + std::to_string(id) + " does not exist");
+        return ERR_NOT_FOUND;
+    }
+    live_[it->second] = 0;  // tombstone: the node stays in the graph and is still walked (:407)
+    id_to_node_.erase(it);
+    --live_count_;
+    return OK;
+}
+
+int HnswIndex::get_vector(uint64_t id, double* out) const
+{
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    auto it = id_to_node_.find(id);
+    if (it == id_to_node_.end()) return ERR_NOT_FOUND;
+    VL_HIP(hipSetDevice(device_));
+    VL_HIP(hipMemcpy(out, store_->device_master() + (uint64_t)it->second * dim_, dim_ * sizeof(double),
+                     hipMemcpyDeviceToHost));
+    return OK;
+}
+
+int HnswIndex::max_id(uint64_t* out) const
+{
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    if (id_to_node_.empty()) return ERR_NOT_FOUND;
+    uint64_t m = 0;
+    for (const auto& kv : id_to_node_) m = std::max(m, kv.first);
+    *out = m;
+    return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// search (src/index/hnsw.rs:415-496)
+// ---------------------------------------------------------------------------------------------
+int HnswIndex::ensure_search_scratch(uint64_t nq, uint32_t ef) const
+{
+    const uint64_t qn = nq * dim_;
+    if (qn > q_cap_) {
+        if (d_q_) (void)hipFree(d_q_);
+        if (h_q_) (void)hipHostFree(h_q_);
+        d_q_ = nullptr;
+        h_q_ = nullptr;
+        q_cap_ = 0;
+        VL_HIP(hipMalloc(reinterpret_cast<void**>(&d_q_), qn * sizeof(double)));
+        VL_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_q_), qn * sizeof(double), hipHostMallocDefault));
+        q_cap_ = qn;
+    }
+    const uint64_t hn = nq * ef;
+    if (hn > hits_cap_) {
+        if (d_hits_) (void)hipFree(d_hits_);
+        if (h_hits_) (void)hipHostFree(h_hits_);
+        d_hits_ = nullptr;
+        h_hits_ = nullptr;
+        hits_cap_ = 0;
+        VL_HIP(hipMalloc(reinterpret_cast<void**>(&d_hits_), hn * sizeof(HnswHit)));
+        VL_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_hits_), hn * sizeof(HnswHit), hipHostMallocDefault));
+        hits_cap_ = hn;
+    }
+    return OK;
+}
+
+int HnswIndex::search(const double* query, uint64_t q_len, uint64_t k, int metric, uint32_t ef, uint64_t* out_ids,
+                      double* out_scores, uint64_t* out_n) const
+{
+    return search_batch(query, 1, q_len, k, metric, ef, out_ids, out_scores, out_n);
+}
+
+int HnswIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_len, uint64_t k, int metric, uint32_t ef,
+                            uint64_t* out_ids, double* out_scores, uint64_t* out_n) const
+{
+    if (!out_n && nq) return ERR_INVALID_ARG;
+    for (uint64_t i = 0; i < nq; ++i) out_n[i] = 0;
+    if (metric < 0 || metric > 3) return ERR_INVALID_ARG;
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    if (q_len != dim_) {  // :416-421, checked even when the index is empty
+        set_dim_mismatch(dim_, q_len);
+        set_last_error("Dimension mismatch: expected " + std::to_string(dim_) + ", got " + std::to_string(q_len));
+        return ERR_DIM_MISMATCH;
+    }
+    if (metric != metric_) {  // :425-430
+        set_last_error("Metric mismatch: the HNSW index was built for metric " + std::to_string(metric_) +
+                       ", search requested " + std::to_string(metric));
+        return ERR_METRIC_MISMATCH;
+    }
+    if (nq == 0 || live_count_ == 0) return OK;                      // :432-434
+    const uint64_t max_candidates = std::min<uint64_t>(k, live_count_);  // :437
+    if (max_candidates == 0) return OK;
+    if (!queries || !out_ids || !out_scores) return ERR_INVALID_ARG;
+    // hnsw.nearest(&q, ef = max_candidates, ..) (:454); an explicit ef widens the beam, never narrows it
+    uint64_t ef_walk = std::max<uint64_t>(max_candidates, ef);
+    if (ef_walk > (uint64_t)HNSW_MAX_EF) {
+        if (max_candidates > (uint64_t)HNSW_MAX_EF) {
+            set_last_error("HNSW search supports k <= 128 in this build");
+            return ERR_INVALID_ARG;
+        }
+        ef_walk = HNSW_MAX_EF;
+    }
+
+    VL_HIP(hipSetDevice(device_));
+    std::lock_guard<std::mutex> sg(search_mu_);
+    VL_TRY(ensure_search_scratch(nq, (uint32_t)ef_walk));
+    std::memcpy(h_q_, queries, nq * dim_ * sizeof(double));
+    VL_HIP(hipMemcpyAsync(d_q_, h_q_, nq * dim_ * sizeof(double), hipMemcpyHostToDevice, stream_));
+    const HnswGraphView g = view();
+    VL_HIP(launch_hnsw_search(stream_, metric_, g, d_q_, (uint32_t)nq, (uint32_t)ef_walk, entry_, max_level_, d_hits_));
+    VL_HIP(hipMemcpyAsync(h_hits_, d_hits_, nq * ef_walk * sizeof(HnswHit), hipMemcpyDeviceToHost, stream_));
+    VL_HIP(hipStreamSynchronize(stream_));
+
+    struct Res {
+        uint64_t id;
+        double score;
+    };
+    std::vector<Res> res;
+    for (uint64_t qi = 0; qi < nq; ++qi) {
+        res.clear();
+        const HnswHit* hits = h_hits_ + qi * ef_walk;
+        // `neighbors` holds max_candidates slots (:442-448): the walk's closest max_candidates
+        for (uint64_t i = 0; i < ef_walk && res.size() < max_candidates; ++i) {
+            const HnswHit& h = hits[i];
+            if (h.node == HNSW_NONE) break;           // :473 filters the !0 sentinels
+            if (h.node >= n_nodes_) {
+                set_last_error("HNSW walk returned an out-of-range node (kernel bug)");
+                return ERR_DEVICE;
+            }
+            if (!live_[h.node]) continue;             // :475 tombstoned nodes are dropped AFTER the walk
+            res.push_back({node_id_[h.node], hnsw_score(h.dist, metric_)});
+        }
+        // Note: like the reference, tombstones can make fewer than k results come back.  Unlike the
+        // reference the slots freed by tombstones are refilled from the rest of the beam when ef > k.
+        std::stable_sort(res.begin(), res.end(), [](const Res& a, const Res& b) { return a.score > b.score; });  // :493
+        const uint64_t m = std::min<uint64_t>(res.size(), k);                                                   // :494
+        for (uint64_t i = 0; i < m; ++i) {
+            out_ids[qi * k + i] = res[i].id;
+            out_scores[qi * k + i] = res[i].score;
+        }
+        out_n[qi] = m;
+    }
+    return OK;
+}
+
+}  // namespace vl

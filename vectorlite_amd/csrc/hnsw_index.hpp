@@ -1,0 +1,98 @@
+// hnsw_index.hpp -- host side of the GPU HNSW index: mirror of the reference's
+// `impl VectorIndex for HNSWIndex` (src/index/hnsw.rs:363-496) above the device graph walk
+// (hnsw.hip).  Rows live in a GpuFlatIndex row store (node index = storage position; deletes are
+// tombstones exactly like the reference, src/index/hnsw.rs:400-414).
+#pragma once
+
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "flat_index.hpp"
+#include "hnsw.hpp"
+
+namespace vl {
+
+// convert_distance_to_similarity(d as f64 / 1000.0, metric) (src/index/hnsw.rs:51-75, :478-479)
+double hnsw_score(uint64_t d_u64, int metric);
+
+struct HnswParams {
+    uint32_t m = 16;                // MAXIMUM_NUMBER_CONNECTIONS   (src/index/hnsw.rs:95-101, default profile)
+    uint32_t m0 = 32;               // MAXIMUM_NUMBER_CONNECTIONS_0 (src/index/hnsw.rs:103-109)
+    uint32_t ef_construction = 128; // own traversal (the crate's value is not visible from the reference)
+    uint64_t seed = 0;
+};
+
+class HnswIndex {
+public:
+    static int create(uint64_t dim, int metric, const HnswParams& p, int device, HnswIndex** out);
+    ~HnswIndex();
+
+    int add(uint64_t id, const double* values, uint64_t len);
+    int add_bulk(const uint64_t* ids, const double* values, uint64_t n, bool values_on_device);
+    int remove(uint64_t id);
+    // ef == 0: the reference's rule ef = min(k, len) (src/index/hnsw.rs:437,454); ef > 0: own extension
+    int search(const double* query, uint64_t q_len, uint64_t k, int metric, uint32_t ef, uint64_t* out_ids,
+               double* out_scores, uint64_t* out_n) const;
+    int search_batch(const double* queries, uint64_t nq, uint64_t q_len, uint64_t k, int metric, uint32_t ef,
+                     uint64_t* out_ids, double* out_scores, uint64_t* out_n) const;
+    uint64_t len() const;
+    uint64_t dimension() const { return dim_; }
+    int metric() const { return metric_; }
+    int get_vector(uint64_t id, double* out) const;
+    int max_id(uint64_t* out) const;
+    uint64_t graph_nodes() const { return n_nodes_; }
+
+private:
+    HnswIndex(uint64_t dim, int metric, const HnswParams& p, int device);
+    int ensure_graph(uint64_t nodes, uint64_t upper_slots);
+    HnswGraphView view() const;
+    int ensure_search_scratch(uint64_t nq, uint32_t ef) const;
+
+    const uint64_t dim_;
+    const int metric_;
+    const HnswParams params_;
+    const int device_;
+    std::unique_ptr<GpuFlatIndex> store_;
+    mutable std::shared_mutex mu_;
+    mutable std::mutex search_mu_;  // walks share the per-wave visited stamps: one walk kernel at a time
+    hipStream_t stream_ = nullptr;
+
+    // device graph
+    uint32_t* d_nbr0_ = nullptr;
+    unsigned long long* d_dist0_ = nullptr;
+    uint32_t* d_cnt0_ = nullptr;
+    uint8_t* d_level_ = nullptr;
+    uint32_t* d_upper_off_ = nullptr;
+    uint32_t* d_nbrU_ = nullptr;
+    unsigned long long* d_distU_ = nullptr;
+    uint32_t* d_cntU_ = nullptr;
+    uint32_t* d_lock_ = nullptr;
+    uint32_t* d_stamps_ = nullptr;
+    uint32_t* d_epochs_ = nullptr;
+    uint64_t g_cap_ = 0, u_cap_ = 0;
+    uint32_t n_slots_ = 0;
+
+    // host bookkeeping
+    std::vector<uint8_t> level_;
+    std::vector<uint32_t> upper_off_;
+    uint64_t n_upper_ = 0;
+    uint32_t entry_ = HNSW_NONE;
+    int max_level_ = -1;
+    uint64_t n_nodes_ = 0;
+    std::unordered_map<uint64_t, uint32_t> id_to_node_;  // live ids only (id_to_index, src/index/hnsw.rs:205)
+    std::vector<uint64_t> node_id_;
+    std::vector<uint8_t> live_;
+    uint64_t live_count_ = 0;
+
+    // search scratch
+    mutable double* d_q_ = nullptr;
+    mutable double* h_q_ = nullptr;
+    mutable HnswHit* d_hits_ = nullptr;
+    mutable HnswHit* h_hits_ = nullptr;
+    mutable uint64_t q_cap_ = 0, hits_cap_ = 0;
+};
+
+}  // namespace vl

@@ -21,6 +21,7 @@
 //     reads stay coalesced) + k_select64 / bitonic sort on (score desc, position asc).
 //   * k_hnsw_dist: the four HNSW distance callbacks, f64 reference order, Rust `as u64` semantics.
 #include "kernels.hpp"
+#include "device_common.hpp"
 
 #include <math.h>
 #include <stdlib.h>
@@ -29,42 +30,8 @@
 #include <type_traits>
 
 namespace vl {
+using namespace dev;
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int WAVE = 64;
-
-__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
-
-// Total order of candidates: higher key first, then lower storage position (the reference's
-// stable sort keeps insertion order on ties: src/index/flat.rs:116, src/client.rs:665-667).
-template <typename K>
-__device__ __forceinline__ bool better(K ka, uint32_t pa, K kb, uint32_t pb)
-{
-    return ka > kb || (ka == kb && pa < pb);
-}
-
-// ---- cross-lane moves without LDS traffic ------------------------------------------------------
-// lane i <- lane i-1 (lane 0 keeps its own value): one DPP wave_shr:1 move per dword.
-__device__ __forceinline__ int wave_shr1_dw(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xF, 0xF, false); }
-__device__ __forceinline__ float wave_shr1(float v) { return __int_as_float(wave_shr1_dw(__float_as_int(v))); }
-__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return (uint32_t)wave_shr1_dw((int)v); }
-__device__ __forceinline__ double wave_shr1(double v)
-{
-    const long long b = __double_as_longlong(v);
-    const int lo = wave_shr1_dw((int)(b & 0xFFFFFFFFll)), hi = wave_shr1_dw((int)(b >> 32));
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-// value of a wave-uniform lane (v_readlane_b32 into an SGPR)
-__device__ __forceinline__ float read_lane(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
-__device__ __forceinline__ uint32_t read_lane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
-__device__ __forceinline__ double read_lane(double v, int lane)
-{
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
 
 template <typename K>
 __device__ __forceinline__ K neg_inf();
@@ -451,76 +418,6 @@ __global__ __launch_bounds__(256) void k_scan_batch(const f32x4* __restrict__ sl
             __syncthreads();
         }
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Reference-order f64 arithmetic (this TU is built with -ffp-contract=off: `a += x * y` is one
-// rounded multiply followed by one rounded add, like rustc's output for src/lib.rs:425-572).
-// ---------------------------------------------------------------------------------------------
-template <int METRIC>
-struct Acc64 {
-    double a, b, c;
-    __device__ __forceinline__ void init()
-    {
-        // cosine folds from (0.0, 0.0, 0.0) (src/lib.rs:428); the `.sum::<f64>()` metrics fold from
-        // the float additive identity -0.0 (core::iter::Sum, rustc >= 1.83; crate edition 2024).
-        a = (METRIC == COSINE) ? 0.0 : -0.0;
-        b = 0.0;
-        c = 0.0;
-    }
-    __device__ __forceinline__ void step(double x, double y)
-    {
-        if (METRIC == COSINE) {
-            a += x * y;
-            b += x * x;
-            c += y * y;
-        } else if (METRIC == EUCLIDEAN) {
-            const double d = x - y;
-            a += d * d;
-        } else if (METRIC == MANHATTAN) {
-            a += fabs(x - y);
-        } else {
-            a += x * y;
-        }
-    }
-    // SimilarityMetric::calculate's return value
-    __device__ __forceinline__ double score() const
-    {
-        if (METRIC == COSINE) {
-            const double na = sqrt(b), nb = sqrt(c);
-            if (na == 0.0 || nb == 0.0) return 0.0;
-            return a / (na * nb);
-        }
-        if (METRIC == EUCLIDEAN) return 1.0 / (1.0 + sqrt(a));
-        if (METRIC == MANHATTAN) return 1.0 / (1.0 + a);
-        return a;
-    }
-};
-
-// Rust `f64 as u64`: truncation toward zero, saturating, NaN -> 0.
-__device__ __forceinline__ unsigned long long rust_as_u64(double v)
-{
-    if (!(v > 0.0)) return 0ull;
-    if (v >= 18446744073709551616.0) return ~0ull;
-    return (unsigned long long)v;
-}
-
-// impl Metric<Vec<f64>>::distance (src/index/hnsw.rs:113-174)
-template <int METRIC>
-__device__ __forceinline__ unsigned long long hnsw_quantise(const Acc64<METRIC>& A)
-{
-    if (METRIC == EUCLIDEAN) return rust_as_u64(sqrt(A.a) * 1000.0);
-    if (METRIC == COSINE) {
-        const double na = sqrt(A.b), nb = sqrt(A.c);
-        if (na == 0.0 || nb == 0.0) return 1000ull;
-        const double cosine_sim = A.a / (na * nb);
-        return rust_as_u64((1.0 - cosine_sim) * 1000.0);
-    }
-    if (METRIC == MANHATTAN) return rust_as_u64(A.a * 1000.0);
-    double d = A.a;  // f64::clamp(-1000, 1000): NaN stays NaN
-    if (d < -1000.0) d = -1000.0;
-    if (d > 1000.0) d = 1000.0;
-    return rust_as_u64(1000.0 - d);
 }
 
 // Rescore up to 64 rows (positions in LDS) against the query: global reads are coalesced along the
