@@ -413,3 +413,79 @@ def test_hnsw_distance_callbacks_bit_exact(V, O):
     assert big.hnsw_distances([-1e300], [0], 1).tolist() == [2 ** 64 - 1]
     assert big.hnsw_distances([1.0], [1], 0).tolist() == [1000]
     assert big.hnsw_distances([float("nan")], [0], 3).tolist() == [0]
+
+
+# ---------------------------------------------------------------------------------------------
+# concurrency (searches under RwLock::read run concurrently in the reference, src/client.rs:398)
+# and size-independent properties at a larger N
+# ---------------------------------------------------------------------------------------------
+def test_concurrent_searches_from_many_threads(V, O):
+    import threading
+    rng = np.random.default_rng(77)
+    n, dim = 50000, 128
+    rows = unit_rows(rng, n, dim)
+    ids = permuted_ids(n)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    Q = unit_rows(rng, 64, dim)
+    want = [ref.search(Q[i], 10, i % 4) for i in range(64)]
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(3):
+                for i in range(t, 64, 8):
+                    gi, gs = gpu.search_arrays(Q[i], 10, i % 4)
+                    if gi.tolist() != want[i][0].tolist() or gs.tolist() != want[i][1].tolist():
+                        errors.append((t, i))
+        except Exception as e:  # pragma: no cover
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert errors == []
+
+
+def test_large_index_properties(V):
+    """N = 2M x 128 (too big for the oracle in a test): fast path == exact path bit for bit,
+    sortedness, idempotence, self-query returns the row itself with score 1, delete removes it."""
+    import torch
+    n, dim = 2_000_000, 128
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(7)
+    idx = V.FlatIndex(dim)
+    idx.reserve(n)
+    for c0 in range(0, n, 500_000):
+        x = torch.randn((500_000, dim), dtype=torch.float64, device="cuda:0", generator=g)
+        x /= torch.linalg.vector_norm(x, dim=1, keepdim=True)
+        idx.add_rows(np.arange(c0, c0 + 500_000, dtype=np.uint64) * 3 + 1, x, validate=False)
+    assert len(idx) == n
+    rng = np.random.default_rng(1)
+    Q = unit_rows(rng, 6, dim)
+    for m in range(4):
+        for qi in range(6):
+            fi, fs = idx.search_arrays(Q[qi], 10, m)
+            assert V.last_path() == V.PATH_FAST
+            fi2, fs2 = idx.search_arrays(Q[qi], 10, m)
+            assert fi.tolist() == fi2.tolist() and fs.tolist() == fs2.tolist()  # idempotent
+            assert all(fs[i - 1] >= fs[i] for i in range(1, 10))               # sorted
+            idx.force_path(V.PATH_EXACT_SELECT)
+            ei, es = idx.search_arrays(Q[qi], 10, m)
+            idx.force_path(0)
+            assert fi.tolist() == ei.tolist() and fs.tolist() == es.tolist(), (m, qi)
+    bi, bs, bn = idx.search_batch(Q, 10, 0)
+    for qi in range(6):
+        fi, fs = idx.search_arrays(Q[qi], 10, 0)
+        assert bi[qi].tolist() == fi.tolist() and bs[qi].tolist() == fs.tolist()
+    probe_id = 1_234_567 * 3 + 1
+    v = idx.get_vector(probe_id).values
+    r = idx.search(v, 3, 0)
+    assert r[0].id == probe_id and abs(r[0].score - 1.0) < 1e-12
+    idx.delete(probe_id)
+    assert len(idx) == n - 1 and idx.get_vector(probe_id) is None
+    r2 = idx.search(v, 3, 0)
+    assert r2[0].id == r[1].id and r2[0].score == r[1].score

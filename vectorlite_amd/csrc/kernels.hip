@@ -287,6 +287,9 @@ __global__ __launch_bounds__(256) void k_scan(const f32x4* __restrict__ slab, co
             inv[u] = 1.0f;
             if (METRIC == COSINE) inv[u] = inv_norm[r];  // issued with the row loads, not after them
         }
+        // every load of this iteration is issued before the first FMA: left alone, the scheduler
+        // trades memory-level parallelism for registers and serialises the loads two at a time
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float a = 0.0f;
