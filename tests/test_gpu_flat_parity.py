@@ -353,6 +353,46 @@ def test_batch_scan_kernel_parity(V, O, dim):
                 assert [int(ids[p]) for p in pos[i]] == ri.tolist()
 
 
+@pytest.mark.parametrize("dim,n", [(128, 9000), (384, 5000), (768, 3000), (100, 4000), (384, 1500)])
+def test_mfma_large_batch_parity(V, O, dim, n):
+    """>= 64 queries per call take the bf16 MFMA candidate filter (cosine, dot); results must still be
+    the oracle's bit for bit, including queries the filter cannot certify (ties, out-of-domain)."""
+    rng = np.random.default_rng(7 * dim + n)
+    nq = 150
+    rows = unit_rows(rng, n, dim)
+    rows[1000:1040] = rows[17]
+    ids = permuted_ids(n)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    Q = unit_rows(rng, nq, dim)
+    Q[3] = rows[17]
+    Q[5] = Q[5] * 1e100
+    Q[9] = 0.0
+    Q[11] = rows[500] * 0.999 + Q[11] * 0.001
+    for name in ("cosine", "dotproduct", "euclidean"):
+        m = M[name]
+        for k in (1, 10, 32):
+            bi, bs, bn = gpu.search_batch(Q, k, m)
+            for i in range(nq):
+                ri, rs = ref.search(Q[i], k, m)
+                assert bn[i] == len(ri)
+                assert bi[i].tolist() == ri.tolist(), (dim, name, k, i)
+                assert bs[i].tolist() == rs.tolist(), (dim, name, k, i)
+    # rows added and deleted after the bf16 slab exists are seen by the next batch
+    extra = unit_rows(rng, 3, dim)
+    for j in range(3):
+        gpu.add(V.Vector(10 ** 9 + j, extra[j]))
+        ref.add(10 ** 9 + j, extra[j])
+    gpu.delete(int(ids[500]))
+    ref.delete(int(ids[500]))
+    Q[0] = extra[1]
+    bi, bs, bn = gpu.search_batch(Q, 10, 0)
+    for i in range(nq):
+        ri, rs = ref.search(Q[i], 10, 0)
+        assert bi[i].tolist() == ri.tolist() and bs[i].tolist() == rs.tolist(), i
+
+
 def test_sharded_index_single_rank_equals_flat(V, O):
     from vectorlite_amd.sharded import ShardedFlatIndex
     rng = np.random.default_rng(31)

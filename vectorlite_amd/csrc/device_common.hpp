@@ -147,5 +147,135 @@ __device__ __forceinline__ unsigned long long walk_key_to_u64(unsigned long long
 }
 
 
+template <typename K>
+__device__ __forceinline__ K neg_inf();
+template <>
+__device__ __forceinline__ float neg_inf<float>() { return -INFINITY; }
+template <>
+__device__ __forceinline__ double neg_inf<double>() { return -(double)INFINITY; }
+
+// ---------------------------------------------------------------------------------------------
+// Sorted top-64 list held one entry per lane (lane 0 = best).
+// ---------------------------------------------------------------------------------------------
+template <typename K>
+struct TopList {
+    K key;
+    uint32_t pos;
+    K thr_key;  // wave-uniform copy of lane 63's entry
+    uint32_t thr_pos;
+
+    __device__ __forceinline__ void init()
+    {
+        key = neg_inf<K>();
+        pos = POS_SENTINEL;
+        // Keep the f64 -inf out of constant propagation: hipcc (ROCm 7.2) otherwise materialises the
+        // wave-uniform threshold with `s_mov_b64 s[..], 0xfff0000000000000`, a 64-bit literal gfx950
+        // cannot encode (it is truncated to 32 bits: the threshold silently becomes +0.0).
+        asm volatile("" : "+v"(key));
+        thr_key = read_lane(key, WAVE - 1);
+        thr_pos = POS_SENTINEL;
+    }
+
+    __device__ __forceinline__ void insert(K k, uint32_t p)
+    {
+        // entries that stay in front of (k, p): a prefix of the lanes because the list is sorted
+        const unsigned long long ahead = __ballot(better<K>(key, pos, k, p));
+        const int idx = __popcll(ahead);
+        const K upk = wave_shr1(key);
+        const uint32_t upp = wave_shr1(pos);
+        const int lane = lane_id();
+        if (lane == idx) {
+            key = k;
+            pos = p;
+        } else if (lane > idx) {
+            key = upk;
+            pos = upp;
+        }
+        thr_key = read_lane(key, WAVE - 1);
+        thr_pos = read_lane(pos, WAVE - 1);
+    }
+
+    // Every lane may offer one (key, pos); lanes are drained in lane order.
+    __device__ __forceinline__ void offer(K k, uint32_t p, bool active)
+    {
+        unsigned long long m = __ballot(active && better<K>(k, p, thr_key, thr_pos));
+        while (m) {
+            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+            m &= m - 1;
+            insert(read_lane(k, src), read_lane(p, src));
+        }
+    }
+
+    // Merge with another sorted list handed over REVERSED (lane i holds its entry 63-i):
+    // the element-wise best is a bitonic sequence holding the 64 best of the union.
+    __device__ __forceinline__ void merge_reversed(K ok, uint32_t op)
+    {
+        if (better<K>(ok, op, key, pos)) {
+            key = ok;
+            pos = op;
+        }
+        const int lane = lane_id();
+#pragma unroll
+        for (int o = WAVE / 2; o >= 1; o >>= 1) {
+            const K k2 = __shfl_xor(key, o);
+            const uint32_t p2 = __shfl_xor(pos, o);
+            const bool lower = (lane & o) == 0;
+            const bool other_better = better<K>(k2, p2, key, pos);
+            if (lower == other_better) {
+                key = k2;
+                pos = p2;
+            }
+        }
+        thr_key = read_lane(key, WAVE - 1);
+        thr_pos = read_lane(pos, WAVE - 1);
+    }
+};
+
+// Tree-merge the NW sorted wave lists of a workgroup through LDS; wave 0 ends with the result.
+template <typename K, typename C, int NW>
+__device__ __forceinline__ void block_merge(TopList<K>& L, C* sh /* [NW][64] */)
+{
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    sh[wave * WAVE + lane].key = L.key;
+    sh[wave * WAVE + lane].pos = L.pos;
+    __syncthreads();
+#pragma unroll
+    for (int s = NW / 2; s >= 1; s >>= 1) {
+        if (wave < s) {
+            const C o = sh[(wave + s) * WAVE + (WAVE - 1 - lane)];
+            L.merge_reversed(o.key, o.pos);
+            sh[wave * WAVE + lane].key = L.key;
+            sh[wave * WAVE + lane].pos = L.pos;
+        }
+        __syncthreads();
+    }
+}
+
+// Fold up to 4 consecutive sorted lists (global memory) into L with bitonic merges.
+template <typename K, typename C>
+__device__ __forceinline__ void fold_lists4(TopList<K>& L, const C* __restrict__ lists, int first, int count)
+{
+    const int lane = lane_id();
+    L.init();
+    C e[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // all loads in flight together
+        const int li = first + (i < count ? i : 0);
+        const int slot = i == 0 ? lane : (KP - 1 - lane);
+        if (count > 0) e[i] = lists[(size_t)li * KP + slot];
+    }
+    if (count > 0) {
+        L.key = e[0].key;
+        L.pos = e[0].pos;
+    }
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < count) L.merge_reversed(e[i].key, e[i].pos);
+    L.thr_key = read_lane(L.key, WAVE - 1);
+    L.thr_pos = read_lane(L.pos, WAVE - 1);
+}
+
+
 }  // namespace dev
 }  // namespace vl

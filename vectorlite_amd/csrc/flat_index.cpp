@@ -82,9 +82,12 @@ Workspace::~Workspace()
                    d_opos, d_out_pos, d_out_scores, d_positions, d_dists};
     for (void* p : dev)
         if (p) (void)hipFree(p);
-    void* host[] = {h_q64, h_result, h_nan};
+    void* host[] = {h_q64, h_result, h_nan, mf_h_q64, mf_h_result};
     for (void* p : host)
         if (p) (void)hipHostFree(p);
+    void* mfd[] = {mf.q_bf16, mf.gmax, mf.thr, mf.cand, mf.cnt, mf_d_q64, mf_lists};
+    for (void* p : mfd)
+        if (p) (void)hipFree(p);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (stream) (void)hipStreamDestroy(stream);
@@ -131,7 +134,7 @@ GpuFlatIndex::~GpuFlatIndex()
     (void)hipSetDevice(device_);
     ws_all_.clear();
     if (mut_stream_) (void)hipStreamSynchronize(mut_stream_);
-    void* dev[] = {d_master_, d_slab_, d_inv_norm_, d_flags_, d_stats_, d_bounce_};
+    void* dev[] = {d_master_, d_slab_, d_inv_norm_, d_flags_, d_stats_, d_bounce_, d_slab16_};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     if (mut_stream_) (void)hipStreamDestroy(mut_stream_);
@@ -192,6 +195,11 @@ int GpuFlatIndex::ensure_capacity(uint64_t rows)
     d_inv_norm_ = inv;
     d_flags_ = fl;
     cap_ = new_cap;
+    if (d_slab16_) {  // rebuilt on demand by the next large batch
+        (void)hipFree(d_slab16_);
+        d_slab16_ = nullptr;
+        slab16_rows_ = 0;
+    }
     return OK;
 }
 
@@ -320,6 +328,7 @@ int GpuFlatIndex::remove_position(uint64_t pos)
         VL_HIP(hipStreamSynchronize(mut_stream_));
     }
     if (row_flags_[pos] & ROW_OUT_OF_DOMAIN) --n_out_of_domain_;
+    if (slab16_rows_ > pos) slab16_rows_ = pos;  // rows behind the hole are re-converted on demand
     ids_.erase(ids_.begin() + pos);
     row_flags_.erase(row_flags_.begin() + pos);
     return OK;
@@ -482,6 +491,25 @@ int GpuFlatIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_le
     if (!batchable) {
         for (uint64_t qi = 0; qi < nq; ++qi) VL_TRY(single(qi, false));
         return OK;
+    }
+
+    // large cosine / dot batches: bf16 MFMA candidate filter; whatever it cannot certify is redone below
+    std::vector<uint8_t> done(nq, 0);
+    const char* mf_env = getenv("VL_MFMA");
+    const bool mfma_on = !(mf_env && mf_env[0] == '0');
+    if (mfma_on && nq >= (uint64_t)MFMA_MIN_BATCH && mfma_scan_supported((uint32_t)dim_, metric)) {
+        VL_TRY(search_batch_mfma(ws, queries, nq, k, k_eff, metric, out_pos, out_ids, out_scores, out_n, &done));
+        uint64_t left = 0;
+        for (uint64_t qi = 0; qi < nq; ++qi) left += done[qi] ? 0 : 1;
+        if (left == 0) {
+            set_last_path(PATH_FAST);
+            return OK;
+        }
+        if (left < nq) {  // few stragglers: answer them one by one on the f32 path
+            for (uint64_t qi = 0; qi < nq; ++qi)
+                if (!done[qi]) VL_TRY(single(qi, false));
+            return OK;
+        }
     }
 
     const bool prof = profile_.load();
@@ -714,6 +742,122 @@ int GpuFlatIndex::run_exact(Workspace* ws, int metric, uint64_t n, uint64_t k_ef
         set_last_path(PATH_EXACT_SELECT);
     } else {
         set_last_path(PATH_EXACT_SORT);
+    }
+    return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// large batches: bf16 MFMA candidate filter (mfma_scan.hip) + the same exact finalize
+// ---------------------------------------------------------------------------------------------
+int GpuFlatIndex::ensure_bf16_slab() const
+{
+    std::lock_guard<std::mutex> g(bf16_mu_);
+    const uint64_t n = ids_.size();
+    const uint32_t ldb = mfma_ldb((uint32_t)dim_);
+    if (!d_slab16_) {
+        VL_HIP(hipMalloc(&d_slab16_, cap_ * (size_t)ldb * 2));
+        slab16_rows_ = 0;
+    }
+    if (slab16_rows_ < n) {
+        char* dst = reinterpret_cast<char*>(d_slab16_) + slab16_rows_ * (size_t)ldb * 2;
+        VL_HIP(launch_rows_bf16(mut_stream_, d_master_ + slab16_rows_ * dim_, n - slab16_rows_, (uint32_t)dim_, dst));
+        VL_HIP(hipStreamSynchronize(mut_stream_));
+        slab16_rows_ = n;
+    }
+    return OK;
+}
+
+int GpuFlatIndex::ensure_mfma_scratch(Workspace* ws) const
+{
+    if (ws->mf.nq_cap) return OK;
+    const size_t nqc = MFMA_MAX_BATCH;
+    const uint32_t ldb = mfma_ldb((uint32_t)dim_);
+    VL_HIP(hipMalloc(&ws->mf.q_bf16, nqc * ldb * 2));
+    VL_TRY(dev_alloc(&ws->mf.gmax, nqc * MFMA_GROUPS));
+    VL_TRY(dev_alloc(&ws->mf.thr, nqc));
+    VL_TRY(dev_alloc(&ws->mf.cand, nqc * MFMA_CAND_CAP));
+    VL_TRY(dev_alloc(&ws->mf.cnt, nqc));
+    VL_TRY(dev_alloc(&ws->mf_d_q64, nqc * (dim_ + 1)));
+    VL_TRY(pinned_alloc(&ws->mf_h_q64, nqc * (dim_ + 1)));
+    VL_TRY(dev_alloc(&ws->mf_lists, nqc * KP));
+    VL_TRY(pinned_alloc(&ws->mf_h_result, nqc));
+    ws->mf.nq_cap = (uint32_t)nqc;
+    return OK;
+}
+
+// Cosine / dot batches of >= MFMA_MIN_BATCH in-domain queries.  done[qi] is set for every query
+// answered here; the caller redoes the others (bound check failed, candidate overflow, ...).
+int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, uint64_t nq, uint64_t k, uint64_t k_eff,
+                                    int metric, uint64_t* out_pos, uint64_t* out_ids, double* out_scores,
+                                    uint64_t* out_n, std::vector<uint8_t>* done) const
+{
+    const uint64_t n = ids_.size();
+    VL_TRY(ensure_bf16_slab());
+    VL_TRY(ensure_mfma_scratch(ws));
+    hipStream_t st = ws->stream;
+    // (2 + u) * u with u = 2^-8 + 2^-23 (f64 -> f32 -> bf16 double rounding), see DESIGN.md
+    const double in_extra = 0.0079;
+    const bool prof = profile_.load();
+    for (uint64_t q0 = 0; q0 < nq; q0 += MFMA_MAX_BATCH) {
+        const uint32_t g = (uint32_t)std::min<uint64_t>(MFMA_MAX_BATCH, nq - q0);
+        double* norms = ws->mf_h_q64 + (size_t)g * dim_;
+        std::vector<uint8_t> in_domain(g);
+        for (uint32_t j = 0; j < g; ++j) {
+            const double* q = queries + (q0 + j) * dim_;
+            double qq = 0.0, qmax = 0.0;
+            bool finite = true;
+            double* dst = ws->mf_h_q64 + (size_t)j * dim_;
+            for (uint64_t i = 0; i < dim_; ++i) {
+                const double v = q[i];
+                dst[i] = v;
+                qq += v * v;
+                const double av = std::fabs(v);
+                if (!(av <= 1.797693134862315708e308)) finite = false;
+                if (av > qmax) qmax = av;
+            }
+            norms[j] = std::sqrt(qq);
+            in_domain[j] = finite && qmax <= DOMAIN_MAX_ABS && (norms[j] == 0.0 || norms[j] >= DOMAIN_MIN_NORM);
+            if (!in_domain[j]) {
+                for (uint64_t i = 0; i < dim_; ++i) dst[i] = 0.0;
+                norms[j] = 0.0;
+            }
+        }
+        VL_HIP(hipMemcpyAsync(ws->mf_d_q64, ws->mf_h_q64, ((size_t)g * dim_ + g) * sizeof(double), hipMemcpyHostToDevice, st));
+        if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
+        VL_HIP(launch_mfma_candidates(st, metric, d_slab16_, d_inv_norm_, ws->mf_d_q64, g, n, (uint32_t)dim_, ws->mf,
+                                      ws->mf_lists));
+        if (prof) VL_HIP(hipEventRecord(ws->ev1, st));
+        VL_HIP(launch_merge_finalize(st, metric, ws->mf_lists, 1, (int)g, d_master_, ws->mf_d_q64,
+                                     ws->mf_d_q64 + (size_t)g * dim_, (uint32_t)dim_, n, (uint32_t)k_eff, max_row_norm_,
+                                     ws->mf_h_result, in_extra));
+        VL_HIP(hipStreamSynchronize(st));
+        if (prof) {
+            float ms = 0.f;
+            VL_HIP(hipEventElapsedTime(&ms, ws->ev0, ws->ev1));
+            std::lock_guard<std::mutex> gl(prof_mu_);
+            prof_n_ += 1;
+            prof_ms_ += ms;
+            prof_bytes_ += n * (uint64_t)mfma_ldb((uint32_t)dim_) * 2;
+        }
+        for (uint32_t j = 0; j < g; ++j) {
+            const uint64_t qi = q0 + j;
+            const SearchResultBlock& r = ws->mf_h_result[j];
+            if (!in_domain[j] || (r.flags & RESULT_NEEDS_EXACT) || r.n_out != k_eff) continue;
+            bool ok = true;
+            for (uint64_t i = 0; i < k_eff; ++i) ok = ok && r.pos[i] < n;
+            if (!ok) {
+                set_last_error("MFMA path returned an out-of-range position (kernel bug)");
+                return ERR_DEVICE;
+            }
+            for (uint64_t i = 0; i < k_eff; ++i) {
+                const uint32_t p = r.pos[i];
+                if (out_pos) out_pos[qi * k + i] = p;
+                if (out_ids) out_ids[qi * k + i] = ids_[p];
+                out_scores[qi * k + i] = r.score[i];
+            }
+            out_n[qi] = k_eff;
+            (*done)[qi] = 1;
+        }
     }
     return OK;
 }

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "mfma_scan.hpp"
 
 namespace vl {
 
@@ -71,6 +72,12 @@ struct Workspace {
     uint64_t* d_dists = nullptr;
     size_t hn_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // large-batch MFMA path (lazy)
+    MfmaScratch mf;
+    double* mf_d_q64 = nullptr;             // [MFMA_MAX_BATCH, dim] queries, then their norms
+    double* mf_h_q64 = nullptr;             // pinned
+    Cand32* mf_lists = nullptr;             // [MFMA_MAX_BATCH, KP]
+    SearchResultBlock* mf_h_result = nullptr;  // pinned [MFMA_MAX_BATCH]
 
     ~Workspace();
 };
@@ -125,6 +132,11 @@ private:
                       uint64_t* out_ids, double* out_scores, uint64_t* out_n, bool skip_fast) const;
     int run_exact(Workspace* ws, int metric, uint64_t n, uint64_t k_eff, std::vector<uint32_t>* pos,
                   std::vector<double>* scores) const;
+    int ensure_bf16_slab() const;            // lazily builds the bf16 slab the MFMA path streams
+    int ensure_mfma_scratch(Workspace* ws) const;
+    int search_batch_mfma(Workspace* ws, const double* queries, uint64_t nq, uint64_t k, uint64_t k_eff, int metric,
+                          uint64_t* out_pos, uint64_t* out_ids, double* out_scores, uint64_t* out_n,
+                          std::vector<uint8_t>* done) const;
 
     const uint64_t dim_;
     const uint32_t ld_;  // slab row stride in floats: dim rounded up to 4 (16-byte vector loads)
@@ -136,6 +148,9 @@ private:
     float* d_slab_ = nullptr;     // [cap, ld]  f32: what the scan streams
     float* d_inv_norm_ = nullptr; // [cap]      f32: 1/|row|, 0 for zero rows
     uint8_t* d_flags_ = nullptr;  // [cap]
+    mutable void* d_slab16_ = nullptr;     // [cap, ldb] bf16: candidate filter of the MFMA batch path (lazy)
+    mutable uint64_t slab16_rows_ = 0;     // rows converted so far (== len() once built)
+    mutable std::mutex bf16_mu_;
     IngestStats* d_stats_ = nullptr;
     uint64_t cap_ = 0;
     hipStream_t mut_stream_ = nullptr;

@@ -80,7 +80,8 @@ hipError_t launch_scan(hipStream_t s, int metric, const float* slab, const float
 // q_norms[nq] the f64 query norms, out[nq] the result blocks.
 hipError_t launch_merge_finalize(hipStream_t s, int metric, Cand32* partials, int n_lists, int nq,
                                  const double* master, const double* q64, const double* q_norms, uint32_t dim,
-                                 uint64_t n_rows, uint32_t k, double max_row_norm, SearchResultBlock* out);
+                                 uint64_t n_rows, uint32_t k, double max_row_norm, SearchResultBlock* out,
+                                 double in_extra = 0.0);
 
 // K3: one slab pass for nq <= SCAN_BATCH_QB queries (q64 is [nq, dim]); lists are written query-major.
 bool scan_batch_supported(uint32_t ld);

@@ -1,0 +1,41 @@
+// mfma_scan.hpp -- launch interface of the bf16 MFMA batched scan (mfma_scan.hip, K4).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "kernels.hpp"
+
+namespace vl {
+
+constexpr int MFMA_GROUPS = 256;       // workgroups (= row groups) of the sampling pass
+constexpr int MFMA_CAND_CAP = 4096;    // candidate buffer entries per query
+constexpr int MFMA_MAX_BATCH = 1024;   // queries per launch sequence (scratch is sized for this)
+constexpr int MFMA_MIN_BATCH = 64;     // below this the f32 batch path is used
+
+// bf16 slab row stride in elements: dim rounded up to the MFMA K step (16)
+inline uint32_t mfma_ldb(uint32_t dim) { return (dim + 15u) & ~15u; }
+
+struct MfmaScratch {
+    void* q_bf16 = nullptr;     // [nq_cap_pad, ldb] bf16
+    int* gmax = nullptr;        // [nq_cap_pad, MFMA_GROUPS]
+    float* thr = nullptr;       // [nq_cap_pad]
+    Cand32* cand = nullptr;     // [nq_cap_pad, MFMA_CAND_CAP]
+    uint32_t* cnt = nullptr;    // [nq_cap_pad]
+    uint32_t nq_cap = 0;
+};
+
+bool mfma_scan_supported(uint32_t dim, int metric);
+
+// f64 master rows [n, dim] -> bf16 rows [n, ldb] (f64 -> f32 -> bf16, round to nearest even)
+hipError_t launch_rows_bf16(hipStream_t s, const double* master, uint64_t n, uint32_t dim, void* out_bf16);
+
+// nq queries (f64 [nq, dim]) against the bf16 slab: writes one sorted top-64 candidate list per query
+// (out_lists[nq][64], the layout k_merge_finalize takes with n_lists = 1).
+hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf16, const float* inv_norm,
+                                  const double* q64, uint32_t nq, uint64_t n_rows, uint32_t dim,
+                                  const MfmaScratch& w, Cand32* out_lists);
+
+}  // namespace vl
