@@ -159,6 +159,17 @@ def main():
     alg_bytes = n * ld * 4  # N_scanned * dim * sizeof(f32) per slab pass
     avg_scan_ms = scan_ms / max(n_launch, 1)
     achieved = alg_bytes / (avg_scan_ms * 1e-3) / 1e9 if n_launch else 0.0
+    # HBM bytes per k_scan launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, gfx950 x2
+    # correction; profiles/traffic.json).  PMC cannot be collected from inside this process, so the
+    # figure is attached only when it was measured on exactly this workload.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            tj = json.load(f)["k_scan"]
+        if tj["workload"] == {"rows": n, "dim": dim, "metric": args.metric}:
+            traffic = tj["traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
     out = {
         "metric": "flat-cosine QPS @ N=10M dim=384 k=10; achieved HBM GB/s vs peak",
         "value": round(qps, 3),
@@ -185,7 +196,7 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "traffic": None,
+            "traffic": traffic,
             "kernel": "k_scan",
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_launch_ms": round(avg_scan_ms, 4),

@@ -17,6 +17,8 @@
 // A query whose check fails (or whose buffer overflows) is redone on the f32 path by the host.
 #include "mfma_scan.hpp"
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "device_common.hpp"
@@ -30,7 +32,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MF_ROWS = 32;  // rows per tile (MFMA M)
-constexpr int MF_QPB = 128;  // queries per workgroup: 4 waves x 32 (MFMA N)
 
 // order-preserving float <-> int (for max over possibly negative keys)
 __device__ __forceinline__ int enc_f(float f)
@@ -40,8 +41,8 @@ __device__ __forceinline__ int enc_f(float f)
 }
 __device__ __forceinline__ float dec_f(int e) { return __int_as_float(e >= 0 ? e : e ^ 0x7FFFFFFF); }
 
-template <int KSTEPS, int MODE, int METRIC>
-__global__ __launch_bounds__(256) void k_mfma_scan(const __bf16* __restrict__ slab16,
+template <int KSTEPS, int MODE, int METRIC, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restrict__ slab16,
                                                    const float* __restrict__ inv_norm,
                                                    const __bf16* __restrict__ q16, uint32_t nq, uint32_t n_tiles,
                                                    uint32_t n_rows, int* __restrict__ gmax, uint32_t n_groups,
@@ -52,7 +53,9 @@ __global__ __launch_bounds__(256) void k_mfma_scan(const __bf16* __restrict__ sl
     constexpr int ROW_BYTES = LDB * 2;
     constexpr int LDS_ROW = ROW_BYTES + 16;     // +16 B: 32 rows land on 16 distinct 4-bank slots
     constexpr int CHUNKS = MF_ROWS * ROW_BYTES / 16;  // 16-byte pieces per tile
-    constexpr int CPT = (CHUNKS + 255) / 256;         // pieces per thread
+    constexpr int NT = NWAVES * 64;                   // threads per workgroup
+    constexpr int MF_QPB = NWAVES * 32;               // queries per workgroup (MFMA N = 32 per wave)
+    constexpr int CPT = (CHUNKS + NT - 1) / NT;       // pieces per thread
     constexpr int CPR = ROW_BYTES / 16;               // pieces per row
     constexpr int NBUF = (2 * MF_ROWS * LDS_ROW <= 60000) ? 2 : 1;  // static LDS stays under 64 KB
     __shared__ __attribute__((aligned(16))) unsigned char a_lds[NBUF][MF_ROWS * LDS_ROW];
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256) void k_mfma_scan(const __bf16* __restrict__ sl
         const uint32_t row0 = tile * MF_ROWS;
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const int c = tid + i * 256;
+            const int c = tid + i * NT;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (c < CHUNKS && row0 + (uint32_t)(c / CPR) < n_rows)
                 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + (size_t)c * 16));
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void k_mfma_scan(const __bf16* __restrict__ sl
     auto write_lds = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const int c = tid + i * 256;
+            const int c = tid + i * NT;
             if (c < CHUNKS) {
                 const int r = c / CPR, cc = c % CPR;
                 *reinterpret_cast<u32x4*>(&a_lds[buf][r * LDS_ROW + cc * 16]) = stage[i];
@@ -242,6 +245,21 @@ __global__ void k_rows_bf16(const double* __restrict__ master, uint64_t n, uint3
 
 #define VL_MFMA_KSTEPS(X) X(8) X(16) X(24) X(32) X(48)
 
+namespace {
+int env_waves()
+{
+    const char* v = getenv("VL_MFMA_WAVES");
+    const int w = v && *v ? atoi(v) : 8;
+    return w == 4 ? 4 : 8;
+}
+int env_grid()
+{
+    const char* v = getenv("VL_MFMA_GRID");
+    const int g = v && *v ? atoi(v) : 512;
+    return g < 1 ? 1 : g;
+}
+}  // namespace
+
 bool mfma_scan_supported(uint32_t dim, int metric)
 {
     if (metric != COSINE && metric != DOT) return false;
@@ -270,7 +288,10 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     if (nq == 0 || n_rows == 0 || n_rows >= 0xFFFFFFFFull) return hipErrorInvalidValue;
     if (!mfma_scan_supported(dim, metric) || nq > w.nq_cap) return hipErrorInvalidValue;
     const uint32_t ldb = mfma_ldb(dim);
-    const uint32_t nq_pad = (nq + MF_QPB - 1) / MF_QPB * MF_QPB;
+    const int nwaves = env_waves();
+    const uint32_t qpb = (uint32_t)nwaves * 32;
+    const uint32_t nq_pad = (nq + qpb - 1) / qpb * qpb;
+    if (nq_pad > w.nq_cap) return hipErrorInvalidValue;
     const uint32_t n_tiles = (uint32_t)((n_rows + MF_ROWS - 1) / MF_ROWS);
     __bf16* q16 = reinterpret_cast<__bf16*>(w.q_bf16);
     const __bf16* slab = reinterpret_cast<const __bf16*>(slab_bf16);
@@ -286,34 +307,33 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     uint32_t sample_tiles = n_tiles / 16;
     if (sample_tiles < (uint32_t)MFMA_GROUPS) sample_tiles = n_tiles < (uint32_t)MFMA_GROUPS ? n_tiles : (uint32_t)MFMA_GROUPS;
     const uint32_t n_groups = sample_tiles < (uint32_t)MFMA_GROUPS ? sample_tiles : (uint32_t)MFMA_GROUPS;
-    const dim3 grid0(n_groups, nq_pad / MF_QPB);
+    const dim3 grid0(n_groups, nq_pad / qpb);
     const uint64_t sample_rows = std::min<uint64_t>((uint64_t)sample_tiles * MF_ROWS, n_rows);
-    const int pass1_blocks = (int)std::min<uint32_t>(n_tiles, 512);
-    const dim3 grid1(pass1_blocks, nq_pad / MF_QPB);
+    const int pass1_blocks = (int)std::min<uint32_t>(n_tiles, (uint32_t)env_grid());
+    const dim3 grid1(pass1_blocks, nq_pad / qpb);
 
-    const bool cosine = metric == COSINE;
     bool launched = false;
-#define VL_LAUNCH(K)                                                                                                    \
-    if (!launched && ldb == (uint32_t)(K * 16)) {                                                                       \
-        if (cosine) {                                                                                                   \
-            hipLaunchKernelGGL((k_mfma_scan<K, 0, COSINE>), grid0, dim3(256), 0, s, slab, inv_norm, q16, nq, sample_tiles, \
-                               (uint32_t)sample_rows, w.gmax, n_groups, (const float*)nullptr, (Cand32*)nullptr,       \
-                               (uint32_t*)nullptr, 0u);                                                                 \
-            hipLaunchKernelGGL(k_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.gmax, n_groups, nq, w.thr);         \
-            hipLaunchKernelGGL((k_mfma_scan<K, 1, COSINE>), grid1, dim3(256), 0, s, slab, inv_norm, q16, nq, n_tiles,   \
-                               (uint32_t)n_rows, (int*)nullptr, 0u, w.thr, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP);     \
-        } else {                                                                                                        \
-            hipLaunchKernelGGL((k_mfma_scan<K, 0, DOT>), grid0, dim3(256), 0, s, slab, inv_norm, q16, nq, sample_tiles, \
-                               (uint32_t)sample_rows, w.gmax, n_groups, (const float*)nullptr, (Cand32*)nullptr,       \
-                               (uint32_t*)nullptr, 0u);                                                                 \
-            hipLaunchKernelGGL(k_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.gmax, n_groups, nq, w.thr);         \
-            hipLaunchKernelGGL((k_mfma_scan<K, 1, DOT>), grid1, dim3(256), 0, s, slab, inv_norm, q16, nq, n_tiles,      \
-                               (uint32_t)n_rows, (int*)nullptr, 0u, w.thr, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP);     \
-        }                                                                                                               \
+#define VL_LAUNCH3(K, MET, NW)                                                                                          \
+    {                                                                                                                   \
+        hipLaunchKernelGGL((k_mfma_scan<K, 0, MET, NW>), grid0, dim3(NW * 64), 0, s, slab, inv_norm, q16, nq,           \
+                           sample_tiles, (uint32_t)sample_rows, w.gmax, n_groups, (const float*)nullptr,               \
+                           (Cand32*)nullptr, (uint32_t*)nullptr, 0u);                                                   \
+        hipLaunchKernelGGL(k_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.gmax, n_groups, nq, w.thr);             \
+        hipLaunchKernelGGL((k_mfma_scan<K, 1, MET, NW>), grid1, dim3(NW * 64), 0, s, slab, inv_norm, q16, nq, n_tiles,  \
+                           (uint32_t)n_rows, (int*)nullptr, 0u, w.thr, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP);         \
         launched = true;                                                                                                \
+    }
+#define VL_LAUNCH(K)                                                            \
+    if (!launched && ldb == (uint32_t)(K * 16)) {                               \
+        if (metric == COSINE) {                                                 \
+            if (nwaves == 8) VL_LAUNCH3(K, COSINE, 8) else VL_LAUNCH3(K, COSINE, 4) \
+        } else {                                                                \
+            if (nwaves == 8) VL_LAUNCH3(K, DOT, 8) else VL_LAUNCH3(K, DOT, 4)   \
+        }                                                                       \
     }
     VL_MFMA_KSTEPS(VL_LAUNCH)
 #undef VL_LAUNCH
+#undef VL_LAUNCH3
     if (!launched) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_select_candidates, dim3(nq), dim3(256), 0, s, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, out_lists);
     return hipGetLastError();
