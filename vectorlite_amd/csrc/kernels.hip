@@ -350,6 +350,14 @@ __device__ __forceinline__ double bound_for_key(float t_key, uint32_t n, double 
     if (METRIC == DOT) {
         return t + (2.0 * (nn + 2.0) * u + in_extra) * R * Q + 1e-12 * (1.0 + R * Q);
     }
+    if (METRIC == EUCLIDEAN && in_extra > 0.0) {
+        // GEMM-form key of the MFMA path: key = 2 x.q - |x|^2 = |q|^2 - |x - q|^2 (real numbers).
+        // |key32 - key| <= 2 (in_extra + (n+2)u) R Q + u R^2 + u (2 R Q + R^2); u-terms doubled.
+        const double err = 2.0 * in_extra * R * Q + 4.0 * (nn + 4.0) * u * (R * Q + R * R);
+        double s_lo = Q * Q - t - err;
+        if (!(s_lo > 0.0)) s_lo = 0.0;
+        return (1.0 / (1.0 + sqrt(s_lo) * (1.0 - 1e-12))) * (1.0 + 1e-15);
+    }
     const double ts = t < 0.0 ? -t : 0.0;  // key = -sum
     double d_lo;
     if (METRIC == EUCLIDEAN) {

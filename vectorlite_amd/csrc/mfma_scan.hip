@@ -43,7 +43,7 @@ __device__ __forceinline__ float dec_f(int e) { return __int_as_float(e >= 0 ? e
 
 template <int KSTEPS, int MODE, int METRIC, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restrict__ slab16,
-                                                   const float* __restrict__ inv_norm,
+                                                   const float* __restrict__ row_aux,
                                                    const __bf16* __restrict__ q16, uint32_t nq, uint32_t n_tiles,
                                                    uint32_t n_rows, int* __restrict__ gmax, uint32_t n_groups,
                                                    const float* __restrict__ thr, Cand32* __restrict__ cand,
@@ -104,7 +104,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
                 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + (size_t)c * 16));
             stage[i] = v;
         }
-        if (tid < MF_ROWS) stage_inv = (METRIC == COSINE && row0 + tid < n_rows) ? inv_norm[row0 + tid] : 1.0f;
+        // per-row scalar of the key: cosine 1/|x| (key = dot * inv), Euclidean |x|^2 (key = 2 dot - |x|^2)
+        if (tid < MF_ROWS) stage_inv = (METRIC != DOT && row0 + tid < n_rows) ? row_aux[row0 + tid] : 1.0f;
     };
     auto write_lds = [&](int buf) {
 #pragma unroll
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
             const uint32_t row = row0 + rl;
             float key = acc[reg];
             if (METRIC == COSINE) key *= inv_lds[buf][rl];
+            if (METRIC == EUCLIDEAN) key = 2.0f * key - inv_lds[buf][rl];  // = |q|^2 - |x - q|^2, |q|^2 is per query
             const bool ok = q_valid && row < n_rows;
             if (MODE == 0) {
                 if (ok) run_max = fmaxf(run_max, key);
@@ -241,6 +243,24 @@ __global__ void k_rows_bf16(const double* __restrict__ master, uint64_t n, uint3
     }
 }
 
+// |row|^2 in f64 (wave per row), rounded once to f32
+__global__ __launch_bounds__(256) void k_rows_sqnorm(const double* __restrict__ master, uint64_t n, uint32_t dim,
+                                                     float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t n_waves = (uint64_t)gridDim.x * 4;
+    for (uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += n_waves) {
+        double ss = 0.0;
+        for (uint32_t c = lane; c < dim; c += 64) {
+            const double v = master[row * dim + c];
+            ss += v * v;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+        if (lane == 0) out[row] = (float)ss;
+    }
+}
+
 }  // namespace
 
 #define VL_MFMA_KSTEPS(X) X(8) X(16) X(24) X(32) X(48)
@@ -262,7 +282,7 @@ int env_grid()
 
 bool mfma_scan_supported(uint32_t dim, int metric)
 {
-    if (metric != COSINE && metric != DOT) return false;
+    if (metric != COSINE && metric != DOT && metric != EUCLIDEAN) return false;
     const uint32_t ldb = mfma_ldb(dim);
     bool ok = false;
 #define VL_CHK(K) ok = ok || (ldb == (uint32_t)(K * 16));
@@ -271,17 +291,20 @@ bool mfma_scan_supported(uint32_t dim, int metric)
     return ok;
 }
 
-hipError_t launch_rows_bf16(hipStream_t s, const double* master, uint64_t n, uint32_t dim, void* out_bf16)
+hipError_t launch_rows_bf16(hipStream_t s, const double* master, uint64_t n, uint32_t dim, void* out_bf16,
+                            float* out_sqnorm)
 {
     if (n == 0) return hipSuccess;
     const uint32_t ldb = mfma_ldb(dim);
     const size_t total = (size_t)n * ldb;
     const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
     hipLaunchKernelGGL(k_rows_bf16, dim3(grid), dim3(256), 0, s, master, n, dim, ldb, reinterpret_cast<__bf16*>(out_bf16));
+    const int g2 = (int)std::min<uint64_t>((n + 3) / 4, 8192);
+    hipLaunchKernelGGL(k_rows_sqnorm, dim3(g2), dim3(256), 0, s, master, n, dim, out_sqnorm);
     return hipGetLastError();
 }
 
-hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf16, const float* inv_norm,
+hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf16, const float* row_aux,
                                   const double* q64, uint32_t nq, uint64_t n_rows, uint32_t dim,
                                   const MfmaScratch& w, Cand32* out_lists)
 {
@@ -315,11 +338,11 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     bool launched = false;
 #define VL_LAUNCH3(K, MET, NW)                                                                                          \
     {                                                                                                                   \
-        hipLaunchKernelGGL((k_mfma_scan<K, 0, MET, NW>), grid0, dim3(NW * 64), 0, s, slab, inv_norm, q16, nq,           \
+        hipLaunchKernelGGL((k_mfma_scan<K, 0, MET, NW>), grid0, dim3(NW * 64), 0, s, slab, row_aux, q16, nq,           \
                            sample_tiles, (uint32_t)sample_rows, w.gmax, n_groups, (const float*)nullptr,               \
                            (Cand32*)nullptr, (uint32_t*)nullptr, 0u);                                                   \
         hipLaunchKernelGGL(k_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.gmax, n_groups, nq, w.thr);             \
-        hipLaunchKernelGGL((k_mfma_scan<K, 1, MET, NW>), grid1, dim3(NW * 64), 0, s, slab, inv_norm, q16, nq, n_tiles,  \
+        hipLaunchKernelGGL((k_mfma_scan<K, 1, MET, NW>), grid1, dim3(NW * 64), 0, s, slab, row_aux, q16, nq, n_tiles,  \
                            (uint32_t)n_rows, (int*)nullptr, 0u, w.thr, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP);         \
         launched = true;                                                                                                \
     }
@@ -327,6 +350,8 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     if (!launched && ldb == (uint32_t)(K * 16)) {                               \
         if (metric == COSINE) {                                                 \
             if (nwaves == 8) VL_LAUNCH3(K, COSINE, 8) else VL_LAUNCH3(K, COSINE, 4) \
+        } else if (metric == EUCLIDEAN) {                                       \
+            if (nwaves == 8) VL_LAUNCH3(K, EUCLIDEAN, 8) else VL_LAUNCH3(K, EUCLIDEAN, 4) \
         } else {                                                                \
             if (nwaves == 8) VL_LAUNCH3(K, DOT, 8) else VL_LAUNCH3(K, DOT, 4)   \
         }                                                                       \
