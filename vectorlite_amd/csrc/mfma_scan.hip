@@ -31,6 +31,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+
 constexpr int MF_ROWS = 32;  // rows per tile (MFMA M)
 
 // order-preserving float <-> int (for max over possibly negative keys)
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
     constexpr int CPR = ROW_BYTES / 16;               // pieces per row
     constexpr int NBUF = (2 * MF_ROWS * LDS_ROW <= 60000) ? 2 : 1;  // static LDS stays under 64 KB
     __shared__ __attribute__((aligned(16))) unsigned char a_lds[NBUF][MF_ROWS * LDS_ROW];
-    __shared__ float inv_lds[NBUF][MF_ROWS];
+    __shared__ __attribute__((aligned(16))) float inv_lds[NBUF][MF_ROWS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -87,13 +88,16 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
         t_step = gridDim.x;
     }
 
-    float thr_q = -INFINITY;
+    float thr_q = INFINITY;  // padding queries never pass
     if (MODE == 1 && q_valid) thr_q = thr[q];
     float run_max = -INFINITY;
 
-    u32x4 stage[CPT];
-    float stage_inv = 0.0f;
-    auto issue_loads = [&](uint32_t tile) {
+    // Register prefetch ring: DEPTH tiles are in flight per workgroup.  One workgroup per CU leaves
+    // only the loop itself to hide the ~2 us HBM latency, and one tile's MFMAs cover ~0.7 us of it.
+    constexpr int DEPTH = (CPT <= 3) ? 4 : 2;
+    u32x4 stage[DEPTH][CPT];
+    float stage_inv[DEPTH];
+    auto issue_loads = [&](uint32_t tile, u32x4(&st)[CPT], float& st_inv) {
         const unsigned char* src = reinterpret_cast<const unsigned char*>(slab16) + (size_t)tile * MF_ROWS * ROW_BYTES;
         const uint32_t row0 = tile * MF_ROWS;
 #pragma unroll
@@ -102,60 +106,105 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
             u32x4 v = {0u, 0u, 0u, 0u};
             if (c < CHUNKS && row0 + (uint32_t)(c / CPR) < n_rows)
                 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + (size_t)c * 16));
-            stage[i] = v;
+            st[i] = v;
         }
         // per-row scalar of the key: cosine 1/|x| (key = dot * inv), Euclidean |x|^2 (key = 2 dot - |x|^2)
-        if (tid < MF_ROWS) stage_inv = (METRIC != DOT && row0 + tid < n_rows) ? row_aux[row0 + tid] : 1.0f;
+        if (tid < MF_ROWS) st_inv = (METRIC != DOT && row0 + tid < n_rows) ? row_aux[row0 + tid] : 1.0f;
     };
-    auto write_lds = [&](int buf) {
+    auto write_lds = [&](int buf, const u32x4(&st)[CPT], float st_inv) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const int c = tid + i * NT;
             if (c < CHUNKS) {
                 const int r = c / CPR, cc = c % CPR;
-                *reinterpret_cast<u32x4*>(&a_lds[buf][r * LDS_ROW + cc * 16]) = stage[i];
+                *reinterpret_cast<u32x4*>(&a_lds[buf][r * LDS_ROW + cc * 16]) = st[i];
             }
         }
-        if (tid < MF_ROWS) inv_lds[buf][tid] = stage_inv;
+        if (tid < MF_ROWS) inv_lds[buf][tid] = st_inv;
     };
 
-    if (t < t_end) issue_loads(t);
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) {
+        stage_inv[j] = 1.0f;
+        if (t + (uint32_t)j * t_step < t_end) issue_loads(t + (uint32_t)j * t_step, stage[j], stage_inv[j]);
+    }
     int buf = 0;
-    for (; t < t_end; t += t_step, buf = (NBUF == 2 ? buf ^ 1 : 0)) {
-        write_lds(buf);
+    for (uint32_t base = t; base < t_end; base += DEPTH * t_step) {
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) {
+        const uint32_t t = base + (uint32_t)j * t_step;
+        if (t >= t_end) break;  // wave-uniform
+        write_lds(buf, stage[j], stage_inv[j]);
         __syncthreads();
-        if (t + t_step < t_end) issue_loads(t + t_step);
+        if (t + DEPTH * t_step < t_end) issue_loads(t + DEPTH * t_step, stage[j], stage_inv[j]);
 
         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // A fragments are read from LDS one GROUP ahead of the MFMAs that consume them: left alone the
+        // compiler reuses one register quad and every MFMA waits out a full LDS round trip
         const unsigned char* arow = &a_lds[buf][col * LDS_ROW + half * 16];
+        constexpr int GS = 4;
+        constexpr int NG = KSTEPS / GS;
+        static_assert(KSTEPS % GS == 0, "K steps come in whole groups");
+        bf16x8 afrag[2][GS];
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + s * 32);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[s], acc, 0, 0, 0);
+        for (int j = 0; j < GS; ++j) afrag[0][j] = *reinterpret_cast<const bf16x8*>(arow + j * 32);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
+#pragma unroll
+                for (int j = 0; j < GS; ++j)
+                    afrag[(g + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(arow + ((g + 1) * GS + j) * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < GS; ++j)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[g & 1][j], bfrag[g * GS + j], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // C layout: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+        // C layout: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5):
+        // registers 4g..4g+3 are the four consecutive rows 8g + 4*half + {0..3}.
+        // Epilogue on the common path = 16 multiplies, a max tree and ONE compare against the
+        // query's threshold; the per-row work only runs for the rare tile that holds a candidate.
         const uint32_t row0 = t * MF_ROWS;
+        float keys[16];
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int rl = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-            const uint32_t row = row0 + rl;
-            float key = acc[reg];
-            if (METRIC == COSINE) key *= inv_lds[buf][rl];
-            if (METRIC == EUCLIDEAN) key = 2.0f * key - inv_lds[buf][rl];  // = |q|^2 - |x - q|^2, |q|^2 is per query
-            const bool ok = q_valid && row < n_rows;
-            if (MODE == 0) {
-                if (ok) run_max = fmaxf(run_max, key);
-            } else if (ok && key >= thr_q) {
-                const uint32_t slot = atomicAdd(&cnt[q], 1u);
-                if (slot < cap) {
-                    Cand32 e;
-                    e.key = key;
-                    e.pos = row;
-                    cand[(size_t)q * cap + slot] = e;
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 aux = *reinterpret_cast<const f32x4*>(&inv_lds[buf][8 * g4 + 4 * half]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float key = acc[4 * g4 + j];
+                if (METRIC == COSINE) key *= aux[j];
+                if (METRIC == EUCLIDEAN) key = 2.0f * key - aux[j];  // = |q|^2 - |x - q|^2, |q|^2 is per query
+                keys[4 * g4 + j] = key;
+            }
+        }
+        if (row0 + MF_ROWS > n_rows) {  // last, partial tile (wave-uniform)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                if (row0 + (uint32_t)((reg & 3) + 8 * (reg >> 2) + 4 * half) >= n_rows) keys[reg] = -INFINITY;
+        }
+        float m = fmaxf(keys[0], keys[1]);
+#pragma unroll
+        for (int reg = 2; reg < 16; ++reg) m = fmaxf(m, keys[reg]);
+        if (MODE == 0) {
+            run_max = fmaxf(run_max, m);
+        } else if (m >= thr_q) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                if (keys[reg] >= thr_q) {
+                    const uint32_t slot = atomicAdd(&cnt[q], 1u);
+                    if (slot < cap) {
+                        Cand32 e;
+                        e.key = keys[reg];
+                        e.pos = row0 + (uint32_t)((reg & 3) + 8 * (reg >> 2) + 4 * half);
+                        cand[(size_t)q * cap + slot] = e;
+                    }
                 }
             }
         }
         if (NBUF == 1) __syncthreads();  // single buffer: everyone is done reading before the next write
+        buf = (NBUF == 2) ? (buf ^ 1) : 0;
+      }
     }
     if (MODE == 0) {
         const float other = __shfl_xor(run_max, 32);  // the two half-waves saw different rows of the same query
@@ -266,10 +315,12 @@ __global__ __launch_bounds__(256) void k_rows_sqnorm(const double* __restrict__ 
 #define VL_MFMA_KSTEPS(X) X(8) X(16) X(24) X(32) X(48)
 
 namespace {
-int env_waves()
+// 8 waves (256 queries per workgroup) while the query fragments leave room for two waves per SIMD;
+// dim >= 768 keeps 192 registers of fragments per lane, so it runs 4 waves with the whole register file
+int env_waves(uint32_t ldb)
 {
     const char* v = getenv("VL_MFMA_WAVES");
-    const int w = v && *v ? atoi(v) : 8;
+    const int w = v && *v ? atoi(v) : (ldb >= 768 ? 4 : 8);
     return w == 4 ? 4 : 8;
 }
 int env_grid()
@@ -311,7 +362,7 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     if (nq == 0 || n_rows == 0 || n_rows >= 0xFFFFFFFFull) return hipErrorInvalidValue;
     if (!mfma_scan_supported(dim, metric) || nq > w.nq_cap) return hipErrorInvalidValue;
     const uint32_t ldb = mfma_ldb(dim);
-    const int nwaves = env_waves();
+    const int nwaves = env_waves(ldb);
     const uint32_t qpb = (uint32_t)nwaves * 32;
     const uint32_t nq_pad = (nq + qpb - 1) / qpb * qpb;
     if (nq_pad > w.nq_cap) return hipErrorInvalidValue;
