@@ -529,3 +529,51 @@ def test_large_index_properties(V):
     assert len(idx) == n - 1 and idx.get_vector(probe_id) is None
     r2 = idx.search(v, 3, 0)
     assert r2[0].id == r[1].id and r2[0].score == r[1].score
+
+
+# ---------------------------------------------------------------------------------------------
+# adversarial near-ties: the f32 / bf16 filters cannot order these rows, the bound check must notice
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("eps", [1e-3, 1e-6, 1e-9, 1e-13])
+def test_near_duplicate_rows_below_filter_precision(V, O, eps):
+    """A cluster of 200 rows that differ from one base row by ~eps per component: their f64 scores
+    are distinct, their f32 (eps <= 1e-9) or bf16 (eps <= 1e-3) keys are not.  Whatever path answers,
+    ids and scores must be the oracle's."""
+    rng = np.random.default_rng(int(-np.log10(eps)))
+    n, dim = 6000, 128
+    rows = unit_rows(rng, n, dim)
+    base = rows[77].copy()
+    cluster = rng.choice(np.arange(100, n), size=200, replace=False)
+    rows[cluster] = base + eps * rng.standard_normal((200, dim))
+    ids = permuted_ids(n)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    queries = [base, base + 0.01 * rng.standard_normal(dim), unit_rows(rng, 1, dim)[0]]
+    for q in queries:
+        for name, m in M.items():
+            for k in (1, 10, 32):
+                assert_same(V, gpu.search_arrays(q, k, m), ref.search(q, k, m), (eps, name, k))
+    Q = np.stack([queries[i % 3] * (1.0 + 0.001 * i) for i in range(96)])  # 96 queries -> MFMA filter
+    for name in ("cosine", "euclidean", "dotproduct", "manhattan"):
+        bi, bs, bn = gpu.search_batch(Q, 10, M[name])
+        for i in range(96):
+            ri, rs = ref.search(Q[i], 10, M[name])
+            assert bi[i].tolist() == ri.tolist() and bs[i].tolist() == rs.tolist(), (eps, name, i)
+
+
+def test_bound_check_survives_random_scales(V, O):
+    """Random row norms over 12 decades and random query scales: the error bound uses the largest row
+    norm and the query norm, so mixed magnitudes are where a wrong bound would show."""
+    rng = np.random.default_rng(2024)
+    dim, n = 64, 3000
+    for trial in range(6):
+        scales = 10.0 ** rng.uniform(-6, 6, size=(n, 1))
+        rows = rng.standard_normal((n, dim)) * scales
+        ids = permuted_ids(n)
+        gpu = V.FlatIndex(dim)
+        gpu.add_rows(ids, rows, validate=False)
+        ref = O.FlatOracle(dim, ids, rows)
+        q = rng.standard_normal(dim) * 10.0 ** rng.uniform(-6, 6)
+        for name, m in M.items():
+            assert_same(V, gpu.search_arrays(q, 10, m), ref.search(q, 10, m), (trial, name))
