@@ -134,7 +134,7 @@ GpuFlatIndex::~GpuFlatIndex()
     (void)hipSetDevice(device_);
     ws_all_.clear();
     if (mut_stream_) (void)hipStreamSynchronize(mut_stream_);
-    void* dev[] = {d_master_, d_slab_, d_inv_norm_, d_flags_, d_stats_, d_bounce_, d_slab16_, d_sqnorm_};
+    void* dev[] = {d_master_, d_slab_, d_inv_norm_, d_flags_, d_stats_, d_bounce_, d_slab16_, d_sqnorm_, d_norm16_};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     if (mut_stream_) (void)hipStreamDestroy(mut_stream_);
@@ -198,8 +198,10 @@ int GpuFlatIndex::ensure_capacity(uint64_t rows)
     if (d_slab16_) {  // rebuilt on demand by the next large batch
         (void)hipFree(d_slab16_);
         (void)hipFree(d_sqnorm_);
+        (void)hipFree(d_norm16_);
         d_slab16_ = nullptr;
         d_sqnorm_ = nullptr;
+        d_norm16_ = nullptr;
         slab16_rows_ = 0;
     }
     return OK;
@@ -759,12 +761,13 @@ int GpuFlatIndex::ensure_bf16_slab() const
     if (!d_slab16_) {
         VL_HIP(hipMalloc(&d_slab16_, cap_ * (size_t)ldb * 2));
         VL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sqnorm_), cap_ * sizeof(float)));
+        VL_HIP(hipMalloc(reinterpret_cast<void**>(&d_norm16_), cap_ * sizeof(float)));
         slab16_rows_ = 0;
     }
     if (slab16_rows_ < n) {
         char* dst = reinterpret_cast<char*>(d_slab16_) + slab16_rows_ * (size_t)ldb * 2;
         VL_HIP(launch_rows_bf16(mut_stream_, d_master_ + slab16_rows_ * dim_, n - slab16_rows_, (uint32_t)dim_, dst,
-                                d_sqnorm_ + slab16_rows_));
+                                d_norm16_ + slab16_rows_, d_sqnorm_ + slab16_rows_));
         VL_HIP(hipStreamSynchronize(mut_stream_));
         slab16_rows_ = n;
     }
@@ -828,8 +831,8 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, uint64
         }
         VL_HIP(hipMemcpyAsync(ws->mf_d_q64, ws->mf_h_q64, ((size_t)g * dim_ + g) * sizeof(double), hipMemcpyHostToDevice, st));
         if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
-        VL_HIP(launch_mfma_candidates(st, metric, d_slab16_, metric == EUCLIDEAN ? d_sqnorm_ : d_inv_norm_,
-                                      ws->mf_d_q64, g, n, (uint32_t)dim_, ws->mf, ws->mf_lists));
+        VL_HIP(launch_mfma_candidates(st, metric, d_slab16_, d_norm16_, d_sqnorm_, ws->mf_d_q64, g, n, (uint32_t)dim_,
+                                      ws->mf, ws->mf_lists));
         if (prof) VL_HIP(hipEventRecord(ws->ev1, st));
         VL_HIP(launch_merge_finalize(st, metric, ws->mf_lists, 1, (int)g, d_master_, ws->mf_d_q64,
                                      ws->mf_d_q64 + (size_t)g * dim_, (uint32_t)dim_, n, (uint32_t)k_eff, max_row_norm_,

@@ -149,6 +149,7 @@ private:
     float* d_inv_norm_ = nullptr; // [cap]      f32: 1/|row|, 0 for zero rows
     uint8_t* d_flags_ = nullptr;  // [cap]
     mutable void* d_slab16_ = nullptr;     // [cap, ldb] bf16: candidate filter of the MFMA batch path (lazy)
+    mutable float* d_norm16_ = nullptr;    // [cap] f32 |row| (the bf16 slab rows are unit-normalised)
     mutable float* d_sqnorm_ = nullptr;    // [cap] f32 |row|^2 for the GEMM-form Euclidean key (with d_slab16_)
     mutable uint64_t slab16_rows_ = 0;     // rows converted so far (== len() once built)
     mutable std::mutex bf16_mu_;

@@ -42,37 +42,53 @@ __device__ __forceinline__ int enc_f(float f)
 }
 __device__ __forceinline__ float dec_f(int e) { return __int_as_float(e >= 0 ? e : e ^ 0x7FFFFFFF); }
 
-template <int KSTEPS, int MODE, int METRIC, int NWAVES>
+template <int KSTEPS, int MODE, int METRIC, int NWAVES, int QT>
 __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restrict__ slab16,
-                                                   const float* __restrict__ row_aux,
+                                                   const float* __restrict__ row_nrm,
+                                                   const float* __restrict__ row_sqn,
                                                    const __bf16* __restrict__ q16, uint32_t nq, uint32_t n_tiles,
                                                    uint32_t n_rows, int* __restrict__ gmax, uint32_t n_groups,
                                                    const float* __restrict__ thr, Cand32* __restrict__ cand,
-                                                   uint32_t* __restrict__ cnt, uint32_t cap)
+                                                   uint32_t* __restrict__ cnt, uint32_t cap, uint32_t ablate)
 {
     constexpr int LDB = KSTEPS * 16;            // bf16 elements per row
     constexpr int ROW_BYTES = LDB * 2;
     constexpr int LDS_ROW = ROW_BYTES + 16;     // +16 B: 32 rows land on 16 distinct 4-bank slots
     constexpr int CHUNKS = MF_ROWS * ROW_BYTES / 16;  // 16-byte pieces per tile
     constexpr int NT = NWAVES * 64;                   // threads per workgroup
-    constexpr int MF_QPB = NWAVES * 32;               // queries per workgroup (MFMA N = 32 per wave)
+    constexpr int MF_QPB = NWAVES * 32 * QT;          // queries per workgroup: QT 32-column MFMA tiles per wave
     constexpr int CPT = (CHUNKS + NT - 1) / NT;       // pieces per thread
     constexpr int CPR = ROW_BYTES / 16;               // pieces per row
-    constexpr int NBUF = (2 * MF_ROWS * LDS_ROW <= 60000) ? 2 : 1;  // static LDS stays under 64 KB
+    // Candidates found in the loop go to a workgroup ring in LDS and are flushed to the per-query
+    // global buffers AFTER the loop: a (rare, conditional) global atomic inside the loop would make
+    // the loop's vmcnt bookkeeping path-dependent and collapse the prefetch ring to depth 1.
+    constexpr int RING = (MODE == 1) ? 1024 : 1;
+    constexpr int NBUF = (2 * MF_ROWS * LDS_ROW + RING * 10 <= 64000) ? 2 : 1;  // static LDS stays under 64 KB
     __shared__ __attribute__((aligned(16))) unsigned char a_lds[NBUF][MF_ROWS * LDS_ROW];
-    __shared__ __attribute__((aligned(16))) float inv_lds[NBUF][MF_ROWS];
+    __shared__ __attribute__((aligned(16))) float inv_lds[NBUF][MF_ROWS];  // |x|   (dot, Euclidean)
+    __shared__ __attribute__((aligned(16))) float sqn_lds[NBUF][MF_ROWS];  // |x|^2 (Euclidean)
+    __shared__ float ring_key[RING];
+    __shared__ uint32_t ring_pos[RING];
+    __shared__ unsigned short ring_q[RING];
+    __shared__ uint32_t ring_cnt;
+    if (threadIdx.x == 0) ring_cnt = 0;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int col = lane & 31, half = lane >> 5;
-    const uint32_t q = blockIdx.y * MF_QPB + wave * 32 + col;  // this lane's query (B column)
-    const bool q_valid = q < nq;
-
-    bf16x8 bfrag[KSTEPS];
+    // this lane's queries (B columns): one per 32-column tile
+    uint32_t q[QT];
+    bool q_valid[QT];
+    bf16x8 bfrag[QT][KSTEPS];
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s)
-        bfrag[s] = *reinterpret_cast<const bf16x8*>(q16 + (size_t)q * LDB + 16 * s + 8 * half);
+    for (int qt = 0; qt < QT; ++qt) {
+        q[qt] = blockIdx.y * MF_QPB + (wave * QT + qt) * 32 + col;
+        q_valid[qt] = q[qt] < nq;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+            bfrag[qt][s] = *reinterpret_cast<const bf16x8*>(q16 + (size_t)q[qt] * LDB + 16 * s + 8 * half);
+    }
 
     // tile schedule: MODE 0 gives every workgroup ONE contiguous range (its maxima describe distinct
     // rows); MODE 1 grid-strides so that all workgroups stream neighbouring tiles
@@ -88,128 +104,225 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
         t_step = gridDim.x;
     }
 
-    float thr_q = INFINITY;  // padding queries never pass
-    if (MODE == 1 && q_valid) thr_q = thr[q];
-    float run_max = -INFINITY;
+    float thr_q[QT], run_max[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        thr_q[qt] = INFINITY;  // padding queries never pass
+        if (MODE == 1 && q_valid[qt]) thr_q[qt] = thr[q[qt]];
+        run_max[qt] = -INFINITY;
+    }
 
     // Register prefetch ring: DEPTH tiles are in flight per workgroup.  One workgroup per CU leaves
-    // only the loop itself to hide the ~2 us HBM latency, and one tile's MFMAs cover ~0.7 us of it.
+    // only the loop itself to hide the ~2 us HBM latency, and one tile's MFMAs cover a fraction of it.
     constexpr int DEPTH = (CPT <= 3) ? 4 : 2;
     u32x4 stage[DEPTH][CPT];
-    float stage_inv[DEPTH];
-    auto issue_loads = [&](uint32_t tile, u32x4(&st)[CPT], float& st_inv) {
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(slab16) + (size_t)tile * MF_ROWS * ROW_BYTES;
+    float stage_inv[DEPTH], stage_sqn[DEPTH];
+    // Loads are UNCONDITIONAL (addresses are clamped instead of predicated): a load under a branch
+    // makes the vmcnt bookkeeping path-dependent and hipcc then drains the whole ring (vmcnt(0))
+    // before every use, which exposes one full HBM latency per tile.
+    static_assert(CHUNKS % NT == 0, "a tile is a whole number of 16-byte pieces per thread");
+    auto issue_loads = [&](uint32_t tile, u32x4(&st)[CPT], float& st_inv, float& st_sqn) {
         const uint32_t row0 = tile * MF_ROWS;
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const int c = tid + i * NT;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (c < CHUNKS && row0 + (uint32_t)(c / CPR) < n_rows)
-                v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + (size_t)c * 16));
-            st[i] = v;
+            uint32_t row = row0 + (uint32_t)(c / CPR);
+            row = row < n_rows ? row : n_rows - 1;  // rows past the end are masked in the epilogue
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(slab16) + (size_t)row * ROW_BYTES +
+                                       (size_t)(c % CPR) * 16;
+            // plain (cacheable) loads on purpose: the workgroups of the other query chunks read the same
+            // tile at about the same time and are served by the XCD's L2 / the Infinity Cache
+            st[i] = *reinterpret_cast<const u32x4*>(src);
         }
-        // per-row scalar of the key: cosine 1/|x| (key = dot * inv), Euclidean |x|^2 (key = 2 dot - |x|^2)
-        if (tid < MF_ROWS) st_inv = (METRIC != DOT && row0 + tid < n_rows) ? row_aux[row0 + tid] : 1.0f;
+        // The slab rows are unit-normalised (cosine needs no per-row scalar at all); dot restores
+        // x.q = (x^.q) |x|, Euclidean uses key = 2 (x^.q) |x| - |x|^2.
+        uint32_t arow_i = row0 + (uint32_t)(tid & (MF_ROWS - 1));
+        arow_i = arow_i < n_rows ? arow_i : n_rows - 1;
+        st_inv = (METRIC != COSINE) ? row_nrm[arow_i] : 1.0f;
+        st_sqn = (METRIC == EUCLIDEAN) ? row_sqn[arow_i] : 0.0f;
     };
-    auto write_lds = [&](int buf, const u32x4(&st)[CPT], float st_inv) {
+    auto write_lds = [&](int buf, const u32x4(&st)[CPT], float st_inv, float st_sqn) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const int c = tid + i * NT;
-            if (c < CHUNKS) {
-                const int r = c / CPR, cc = c % CPR;
-                *reinterpret_cast<u32x4*>(&a_lds[buf][r * LDS_ROW + cc * 16]) = st[i];
-            }
+            const int r = c / CPR, cc = c % CPR;
+            *reinterpret_cast<u32x4*>(&a_lds[buf][r * LDS_ROW + cc * 16]) = st[i];
         }
-        if (tid < MF_ROWS) inv_lds[buf][tid] = st_inv;
+        if (METRIC != COSINE && tid < MF_ROWS) inv_lds[buf][tid] = st_inv;
+        if (METRIC == EUCLIDEAN && tid < MF_ROWS) sqn_lds[buf][tid] = st_sqn;
     };
 
+    if (t >= t_end) {  // nothing to do for this workgroup (uniform); MODE 0 still reports -inf maxima
+        if (MODE == 0) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+                if (q_valid[qt] && half == 0 && blockIdx.x < n_groups)
+                    gmax[(size_t)q[qt] * n_groups + blockIdx.x] = enc_f(-INFINITY);
+        }
+        return;
+    }
+    const uint32_t t_last = t + ((t_end - 1 - t) / t_step) * t_step;  // last tile of this workgroup
 #pragma unroll
     for (int j = 0; j < DEPTH; ++j) {
-        stage_inv[j] = 1.0f;
-        if (t + (uint32_t)j * t_step < t_end) issue_loads(t + (uint32_t)j * t_step, stage[j], stage_inv[j]);
+        const uint32_t pt = t + (uint32_t)j * t_step;
+        issue_loads(pt < t_end ? pt : t_last, stage[j], stage_inv[j], stage_sqn[j]);
     }
     int buf = 0;
-    for (uint32_t base = t; base < t_end; base += DEPTH * t_step) {
-#pragma unroll
-      for (int j = 0; j < DEPTH; ++j) {
-        const uint32_t t = base + (uint32_t)j * t_step;
-        if (t >= t_end) break;  // wave-uniform
-        write_lds(buf, stage[j], stage_inv[j]);
+    // Ring flush: the only global atomics of the kernel.  It runs at trip boundaries (where hipcc
+    // drains vmcnt anyway) when the ring is half full, and once after the loop.
+    auto flush_ring = [&]() {
         __syncthreads();
-        if (t + DEPTH * t_step < t_end) issue_loads(t + DEPTH * t_step, stage[j], stage_inv[j]);
+        const uint32_t total = ring_cnt;
+        const uint32_t n_ring = total < (uint32_t)RING ? total : (uint32_t)RING;
+        for (uint32_t i = tid; i < n_ring; i += NT) {
+            const uint32_t qq = blockIdx.y * MF_QPB + ring_q[i];
+            const uint32_t slot = atomicAdd(&cnt[qq], 1u);
+            if (slot < cap) {
+                Cand32 e;
+                e.key = ring_key[i];
+                e.pos = ring_pos[i];
+                cand[(size_t)qq * cap + slot] = e;
+            }
+        }
+        if (total > (uint32_t)RING && tid < MF_QPB) {  // ring overflow: these queries are redone by the host
+            const uint32_t qq = blockIdx.y * MF_QPB + tid;
+            if (qq < nq) atomicAdd(&cnt[qq], cap + 1u);
+        }
+        __syncthreads();
+        if (tid == 0) ring_cnt = 0;
+        __syncthreads();
+    };
+    // hipcc drains the ring (vmcnt(0)) at the loop header but uses counted waits inside straight-line
+    // code, so one trip covers UNROLL * DEPTH tiles: one drain per 16 tiles instead of one per 4.
+    constexpr int UNROLL = 4;
+    for (uint32_t base = t; base < t_end; base += UNROLL * DEPTH * t_step) {
+#pragma unroll
+        for (int jj2 = 0; jj2 < UNROLL * DEPTH; ++jj2) {
+            const int j = jj2 % DEPTH;
+            // No early exit: the tail repeats the last tile with its results masked, so that every
+            // trip issues the same loads and hipcc can use counted vmcnt waits (a ring, not a drain).
+            const uint32_t tile_raw = base + (uint32_t)jj2 * t_step;
+            const bool tile_live = tile_raw < t_end;
+            const uint32_t tile = tile_live ? tile_raw : t_last;
+            write_lds(buf, stage[j], stage_inv[j], stage_sqn[j]);
+            __syncthreads();
+            {
+                const uint32_t nt = tile_raw + DEPTH * t_step;  // refill the slot just consumed (clamped at the tail)
+                issue_loads(nt < t_end ? nt : t_last, stage[j], stage_inv[j], stage_sqn[j]);
+            }
 
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        // A fragments are read from LDS one GROUP ahead of the MFMAs that consume them: left alone the
-        // compiler reuses one register quad and every MFMA waits out a full LDS round trip
-        const unsigned char* arow = &a_lds[buf][col * LDS_ROW + half * 16];
-        constexpr int GS = 4;
-        constexpr int NG = KSTEPS / GS;
-        static_assert(KSTEPS % GS == 0, "K steps come in whole groups");
-        bf16x8 afrag[2][GS];
+            f32x16 acc[QT];
 #pragma unroll
-        for (int j = 0; j < GS; ++j) afrag[0][j] = *reinterpret_cast<const bf16x8*>(arow + j * 32);
+            for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) {
+                for (int r = 0; r < 16; ++r) acc[qt][r] = 0.0f;
+            // A fragments are read from LDS one GROUP ahead of the MFMAs that consume them (left alone
+            // the compiler reuses one register quad and every MFMA waits out an LDS round trip); each
+            // fragment feeds QT MFMAs.
+            const unsigned char* arow = &a_lds[buf][col * LDS_ROW + half * 16];
+            constexpr int GS = 4;
+            constexpr int NG = KSTEPS / GS;
+            static_assert(KSTEPS % GS == 0, "K steps come in whole groups");
+            bf16x8 afrag[2][GS];
+            if (!(ablate & 2u)) {
 #pragma unroll
-                for (int j = 0; j < GS; ++j)
-                    afrag[(g + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(arow + ((g + 1) * GS + j) * 32);
+            for (int jj = 0; jj < GS; ++jj) afrag[0][jj] = *reinterpret_cast<const bf16x8*>(arow + jj * 32);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) {
+#pragma unroll
+                    for (int jj = 0; jj < GS; ++jj)
+                        afrag[(g + 1) & 1][jj] = *reinterpret_cast<const bf16x8*>(arow + ((g + 1) * GS + jj) * 32);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int jj = 0; jj < GS; ++jj)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[g & 1][jj], bfrag[qt][g * GS + jj],
+                                                                          acc[qt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            }  // ablate & 2
+            // C layout: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5):
+            // registers 4g..4g+3 are the four consecutive rows 8g + 4*half + {0..3}.
+            // Epilogue on the common path = 16 multiplies, a max tree and ONE compare against the
+            // query's threshold; the per-row work only runs for the rare tile that holds a candidate.
+            const uint32_t row0 = tile * MF_ROWS;
+            if (ablate & 1u) {
 #pragma unroll
-            for (int j = 0; j < GS; ++j)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[g & 1][j], bfrag[g * GS + j], acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // C layout: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5):
-        // registers 4g..4g+3 are the four consecutive rows 8g + 4*half + {0..3}.
-        // Epilogue on the common path = 16 multiplies, a max tree and ONE compare against the
-        // query's threshold; the per-row work only runs for the rare tile that holds a candidate.
-        const uint32_t row0 = t * MF_ROWS;
-        float keys[16];
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 aux = *reinterpret_cast<const f32x4*>(&inv_lds[buf][8 * g4 + 4 * half]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float key = acc[4 * g4 + j];
-                if (METRIC == COSINE) key *= aux[j];
-                if (METRIC == EUCLIDEAN) key = 2.0f * key - aux[j];  // = |q|^2 - |x - q|^2, |q|^2 is per query
-                keys[4 * g4 + j] = key;
+                for (int qt = 0; qt < QT; ++qt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("" ::"v"(acc[qt]));  // keep the MFMA results live
+#endif
+                }
+                if (NBUF == 1) __syncthreads();
+                buf = (NBUF == 2) ? (buf ^ 1) : 0;
+                continue;
             }
-        }
-        if (row0 + MF_ROWS > n_rows) {  // last, partial tile (wave-uniform)
+            f32x4 aux[4], aux2[4];
+            if (METRIC != COSINE) {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg)
-                if (row0 + (uint32_t)((reg & 3) + 8 * (reg >> 2) + 4 * half) >= n_rows) keys[reg] = -INFINITY;
-        }
-        float m = fmaxf(keys[0], keys[1]);
+                for (int g4 = 0; g4 < 4; ++g4) aux[g4] = *reinterpret_cast<const f32x4*>(&inv_lds[buf][8 * g4 + 4 * half]);
+            }
+            if (METRIC == EUCLIDEAN) {
 #pragma unroll
-        for (int reg = 2; reg < 16; ++reg) m = fmaxf(m, keys[reg]);
-        if (MODE == 0) {
-            run_max = fmaxf(run_max, m);
-        } else if (m >= thr_q) {
+                for (int g4 = 0; g4 < 4; ++g4) aux2[g4] = *reinterpret_cast<const f32x4*>(&sqn_lds[buf][8 * g4 + 4 * half]);
+            }
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                if (keys[reg] >= thr_q) {
-                    const uint32_t slot = atomicAdd(&cnt[q], 1u);
-                    if (slot < cap) {
-                        Cand32 e;
-                        e.key = keys[reg];
-                        e.pos = row0 + (uint32_t)((reg & 3) + 8 * (reg >> 2) + 4 * half);
-                        cand[(size_t)q * cap + slot] = e;
+            for (int qt = 0; qt < QT; ++qt) {
+                float keys[16];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        float key = acc[qt][4 * g4 + jj];                                   // cosine: x^.q
+                        if (METRIC == DOT) key *= aux[g4][jj];                              // x.q
+                        if (METRIC == EUCLIDEAN) key = 2.0f * key * aux[g4][jj] - aux2[g4][jj];  // |q|^2 - |x - q|^2
+                        keys[4 * g4 + jj] = key;
+                    }
+                }
+                if (row0 + MF_ROWS > n_rows || !tile_live) {  // partial last tile / repeated tail tile (wave-uniform)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        if (!tile_live || row0 + (uint32_t)((reg & 3) + 8 * (reg >> 2) + 4 * half) >= n_rows)
+                            keys[reg] = -INFINITY;
+                }
+                float m = fmaxf(keys[0], keys[1]);
+#pragma unroll
+                for (int reg = 2; reg < 16; ++reg) m = fmaxf(m, keys[reg]);
+                if (MODE == 0) {
+                    run_max[qt] = fmaxf(run_max[qt], m);
+                } else if (m >= thr_q[qt]) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        if (keys[reg] >= thr_q[qt]) {
+                            const uint32_t slot = atomicAdd(&ring_cnt, 1u);  // LDS atomic
+                            if (slot < (uint32_t)RING) {
+                                ring_key[slot] = keys[reg];
+                                ring_pos[slot] = row0 + (uint32_t)((reg & 3) + 8 * (reg >> 2) + 4 * half);
+                                ring_q[slot] = (unsigned short)((wave * QT + qt) * 32 + col);
+                            }
+                        }
                     }
                 }
             }
+            if (NBUF == 1) __syncthreads();  // single buffer: everyone is done reading before the next write
+            buf = (NBUF == 2) ? (buf ^ 1) : 0;
         }
-        if (NBUF == 1) __syncthreads();  // single buffer: everyone is done reading before the next write
-        buf = (NBUF == 2) ? (buf ^ 1) : 0;
-      }
+        if (MODE == 1) {
+            __syncthreads();
+            if (ring_cnt >= (uint32_t)(RING / 2)) flush_ring();  // workgroup-uniform
+        }
     }
+    if (MODE == 1) flush_ring();  // whatever the last trips left behind
     if (MODE == 0) {
-        const float other = __shfl_xor(run_max, 32);  // the two half-waves saw different rows of the same query
-        run_max = fmaxf(run_max, other);
-        if (q_valid && half == 0 && blockIdx.x < n_groups) gmax[(size_t)q * n_groups + blockIdx.x] = enc_f(run_max);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const float other = __shfl_xor(run_max[qt], 32);  // the two half-waves saw different rows of one query
+            const float mx = fmaxf(run_max[qt], other);
+            if (q_valid[qt] && half == 0 && blockIdx.x < n_groups) gmax[(size_t)q[qt] * n_groups + blockIdx.x] = enc_f(mx);
+        }
     }
 }
 
@@ -279,22 +392,11 @@ __global__ void k_queries_bf16(const double* __restrict__ q64, uint32_t nq, uint
     }
 }
 
-// f64 master rows -> bf16 slab rows [n, ldb]
-__global__ void k_rows_bf16(const double* __restrict__ master, uint64_t n, uint32_t dim, uint32_t ldb,
-                            __bf16* __restrict__ out)
-{
-    const size_t total = (size_t)n * ldb;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const uint64_t r = i / ldb;
-        const uint32_t c = (uint32_t)(i % ldb);
-        const float v = c < dim ? (float)master[r * dim + c] : 0.0f;
-        out[i] = (__bf16)v;
-    }
-}
-
-// |row|^2 in f64 (wave per row), rounded once to f32
-__global__ __launch_bounds__(256) void k_rows_sqnorm(const double* __restrict__ master, uint64_t n, uint32_t dim,
-                                                     float* __restrict__ out)
+// f64 master rows -> UNIT-NORMALISED bf16 slab rows [n, ldb] (x/|x| in f64, then f32, then bf16 RNE;
+// zero rows stay zero), plus |row| and |row|^2 rounded once to f32.  One wave per row.
+__global__ __launch_bounds__(256) void k_rows_bf16(const double* __restrict__ master, uint64_t n, uint32_t dim,
+                                                   uint32_t ldb, __bf16* __restrict__ out, float* __restrict__ out_nrm,
+                                                   float* __restrict__ out_sqn)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t n_waves = (uint64_t)gridDim.x * 4;
@@ -306,7 +408,16 @@ __global__ __launch_bounds__(256) void k_rows_sqnorm(const double* __restrict__ 
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
-        if (lane == 0) out[row] = (float)ss;
+        const double nrm = sqrt(ss);
+        const double inv = nrm > 0.0 ? 1.0 / nrm : 0.0;
+        for (uint32_t c = lane; c < ldb; c += 64) {
+            const float v = c < dim ? (float)(master[row * dim + c] * inv) : 0.0f;
+            out[row * ldb + c] = (__bf16)v;
+        }
+        if (lane == 0) {
+            out_nrm[row] = (float)nrm;
+            out_sqn[row] = (float)ss;
+        }
     }
 }
 
@@ -315,18 +426,27 @@ __global__ __launch_bounds__(256) void k_rows_sqnorm(const double* __restrict__ 
 #define VL_MFMA_KSTEPS(X) X(8) X(16) X(24) X(32) X(48)
 
 namespace {
-// 8 waves (256 queries per workgroup) while the query fragments leave room for two waves per SIMD;
-// dim >= 768 keeps 192 registers of fragments per lane, so it runs 4 waves with the whole register file
-int env_waves(uint32_t ldb)
+// Launch shape of k_mfma_scan: 8 waves x 1 query tile (two waves share a SIMD), or 4 waves x 2 query
+// tiles (one wave per SIMD with the whole register file, every A fragment feeds two MFMAs).
+// dim >= 768 keeps 192 registers of fragments per tile, so it runs 4 waves x 1 tile.
+int env_shape(uint32_t ldb)
 {
-    const char* v = getenv("VL_MFMA_WAVES");
-    const int w = v && *v ? atoi(v) : (ldb >= 768 ? 4 : 8);
-    return w == 4 ? 4 : 8;
+    const char* v = getenv("VL_MFMA_SHAPE");
+    const int want = v && *v ? atoi(v) : 0;
+    if (ldb >= 768) return 41;
+    if (want == 81 || want == 42 || want == 41) return want;
+    return 81;
 }
-int env_grid()
+int env_grid(uint32_t n_chunks)
 {
     const char* v = getenv("VL_MFMA_GRID");
-    const int g = v && *v ? atoi(v) : 512;
+    int g = v && *v ? atoi(v) : 0;
+    if (g <= 0) {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        g = cus / (int)(n_chunks ? n_chunks : 1);
+    }
     return g < 1 ? 1 : g;
 }
 }  // namespace
@@ -343,27 +463,28 @@ bool mfma_scan_supported(uint32_t dim, int metric)
 }
 
 hipError_t launch_rows_bf16(hipStream_t s, const double* master, uint64_t n, uint32_t dim, void* out_bf16,
-                            float* out_sqnorm)
+                            float* out_norm, float* out_sqnorm)
 {
     if (n == 0) return hipSuccess;
     const uint32_t ldb = mfma_ldb(dim);
-    const size_t total = (size_t)n * ldb;
-    const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
-    hipLaunchKernelGGL(k_rows_bf16, dim3(grid), dim3(256), 0, s, master, n, dim, ldb, reinterpret_cast<__bf16*>(out_bf16));
-    const int g2 = (int)std::min<uint64_t>((n + 3) / 4, 8192);
-    hipLaunchKernelGGL(k_rows_sqnorm, dim3(g2), dim3(256), 0, s, master, n, dim, out_sqnorm);
+    const int grid = (int)std::min<uint64_t>((n + 3) / 4, 16384);
+    hipLaunchKernelGGL(k_rows_bf16, dim3(grid), dim3(256), 0, s, master, n, dim, ldb, reinterpret_cast<__bf16*>(out_bf16),
+                       out_norm, out_sqnorm);
     return hipGetLastError();
 }
 
-hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf16, const float* row_aux,
+hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf16, const float* row_norm,
+                                  const float* row_sqnorm,
                                   const double* q64, uint32_t nq, uint64_t n_rows, uint32_t dim,
                                   const MfmaScratch& w, Cand32* out_lists)
 {
     if (nq == 0 || n_rows == 0 || n_rows >= 0xFFFFFFFFull) return hipErrorInvalidValue;
     if (!mfma_scan_supported(dim, metric) || nq > w.nq_cap) return hipErrorInvalidValue;
     const uint32_t ldb = mfma_ldb(dim);
-    const int nwaves = env_waves(ldb);
-    const uint32_t qpb = (uint32_t)nwaves * 32;
+    // launch shape: (waves per workgroup, 32-query tiles per wave); 256 queries per workgroup
+    const int shape = env_shape(ldb);  // 81 = 8 waves x 1 tile, 42 = 4 waves x 2 tiles, 41 = 4 waves x 1 tile
+    const int nwaves = shape / 10, qt = shape % 10;
+    const uint32_t qpb = (uint32_t)nwaves * 32 * (uint32_t)qt;
     const uint32_t nq_pad = (nq + qpb - 1) / qpb * qpb;
     if (nq_pad > w.nq_cap) return hipErrorInvalidValue;
     const uint32_t n_tiles = (uint32_t)((n_rows + MF_ROWS - 1) / MF_ROWS);
@@ -383,32 +504,40 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     const uint32_t n_groups = sample_tiles < (uint32_t)MFMA_GROUPS ? sample_tiles : (uint32_t)MFMA_GROUPS;
     const dim3 grid0(n_groups, nq_pad / qpb);
     const uint64_t sample_rows = std::min<uint64_t>((uint64_t)sample_tiles * MF_ROWS, n_rows);
-    const int pass1_blocks = (int)std::min<uint32_t>(n_tiles, (uint32_t)env_grid());
+    // all query chunks of a launch are co-resident (one workgroup per CU) and walk the same tile
+    // sequence, so a tile is fetched from HBM once and served to the other chunks by L2 / Infinity Cache
+    const uint32_t n_chunks = nq_pad / qpb;
+    const int pass1_blocks = (int)std::min<uint32_t>(n_tiles, (uint32_t)env_grid(n_chunks));
     const dim3 grid1(pass1_blocks, nq_pad / qpb);
 
+    const char* abl = getenv("VL_MFMA_ABLATE");
+    const uint32_t ablate = abl && *abl ? (uint32_t)atoi(abl) : 0u;  // diagnostics only: 1 = no epilogue, 2 = no MFMA
     bool launched = false;
-#define VL_LAUNCH3(K, MET, NW)                                                                                          \
+#define VL_LAUNCH3(K, MET, NW, QTT)                                                                                     \
     {                                                                                                                   \
-        hipLaunchKernelGGL((k_mfma_scan<K, 0, MET, NW>), grid0, dim3(NW * 64), 0, s, slab, row_aux, q16, nq,           \
+        hipLaunchKernelGGL((k_mfma_scan<K, 0, MET, NW, QTT>), grid0, dim3(NW * 64), 0, s, slab, row_norm, row_sqnorm, q16, nq,       \
                            sample_tiles, (uint32_t)sample_rows, w.gmax, n_groups, (const float*)nullptr,               \
-                           (Cand32*)nullptr, (uint32_t*)nullptr, 0u);                                                   \
+                           (Cand32*)nullptr, (uint32_t*)nullptr, 0u, 0u);                                               \
         hipLaunchKernelGGL(k_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.gmax, n_groups, nq, w.thr);             \
-        hipLaunchKernelGGL((k_mfma_scan<K, 1, MET, NW>), grid1, dim3(NW * 64), 0, s, slab, row_aux, q16, nq, n_tiles,  \
-                           (uint32_t)n_rows, (int*)nullptr, 0u, w.thr, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP);         \
+        hipLaunchKernelGGL((k_mfma_scan<K, 1, MET, NW, QTT>), grid1, dim3(NW * 64), 0, s, slab, row_norm, row_sqnorm, q16, nq,       \
+                           n_tiles, (uint32_t)n_rows, (int*)nullptr, 0u, w.thr, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, ablate); \
         launched = true;                                                                                                \
     }
-#define VL_LAUNCH(K)                                                            \
-    if (!launched && ldb == (uint32_t)(K * 16)) {                               \
-        if (metric == COSINE) {                                                 \
-            if (nwaves == 8) VL_LAUNCH3(K, COSINE, 8) else VL_LAUNCH3(K, COSINE, 4) \
-        } else if (metric == EUCLIDEAN) {                                       \
-            if (nwaves == 8) VL_LAUNCH3(K, EUCLIDEAN, 8) else VL_LAUNCH3(K, EUCLIDEAN, 4) \
-        } else {                                                                \
-            if (nwaves == 8) VL_LAUNCH3(K, DOT, 8) else VL_LAUNCH3(K, DOT, 4)   \
-        }                                                                       \
+#define VL_LAUNCH2(K, MET)                                        \
+    {                                                             \
+        if (shape == 81) VL_LAUNCH3(K, MET, 8, 1)                 \
+        else if (shape == 42) VL_LAUNCH3(K, MET, 4, 2)            \
+        else VL_LAUNCH3(K, MET, 4, 1)                             \
+    }
+#define VL_LAUNCH(K)                                              \
+    if (!launched && ldb == (uint32_t)(K * 16)) {                 \
+        if (metric == COSINE) VL_LAUNCH2(K, COSINE)               \
+        else if (metric == EUCLIDEAN) VL_LAUNCH2(K, EUCLIDEAN)    \
+        else VL_LAUNCH2(K, DOT)                                   \
     }
     VL_MFMA_KSTEPS(VL_LAUNCH)
 #undef VL_LAUNCH
+#undef VL_LAUNCH2
 #undef VL_LAUNCH3
     if (!launched) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_select_candidates, dim3(nq), dim3(256), 0, s, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, out_lists);

@@ -29,15 +29,16 @@ struct MfmaScratch {
 
 bool mfma_scan_supported(uint32_t dim, int metric);
 
-// f64 master rows [n, dim] -> bf16 rows [n, ldb] (f64 -> f32 -> bf16, round to nearest even) and
-// |row|^2 (f64 sum, rounded once to f32)
+// f64 master rows [n, dim] -> UNIT-NORMALISED bf16 rows [n, ldb] (x/|x| in f64 -> f32 -> bf16, round to
+// nearest even), |row| and |row|^2 (f64, rounded once to f32)
 hipError_t launch_rows_bf16(hipStream_t s, const double* master, uint64_t n, uint32_t dim, void* out_bf16,
-                            float* out_sqnorm);
+                            float* out_norm, float* out_sqnorm);
 
 // nq queries (f64 [nq, dim]) against the bf16 slab: writes one sorted top-64 candidate list per query
 // (out_lists[nq][64], the layout k_merge_finalize takes with n_lists = 1).
-// row_aux: cosine 1/|row| (inv_norm), Euclidean |row|^2, dot unused.
-hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf16, const float* row_aux,
+// row_norm / row_sqnorm: the arrays launch_rows_bf16 wrote (dot and Euclidean keys need them).
+hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf16, const float* row_norm,
+                                  const float* row_sqnorm,
                                   const double* q64, uint32_t nq, uint64_t n_rows, uint32_t dim,
                                   const MfmaScratch& w, Cand32* out_lists);
 
