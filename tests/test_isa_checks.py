@@ -52,3 +52,32 @@ def test_scan_kernel_streams_with_16_byte_nontemporal_loads(device_asm):
     meta = re.search(r"\.name:\s+_ZN2vl12_GLOBAL__N_16k_scanILi0ELi8ELi12ELi1E.*?\.vgpr_count:\s+(\d+)", device_asm, re.S)
     if meta:
         assert int(meta.group(1)) <= 128
+
+
+def test_mfma_scan_default_shapes_do_not_spill():
+    """The batched bf16 MFMA kernels keep 96-192 registers of query fragments per lane; a scheduling
+    change once made the sampling pass spill 5000 registers (2.4x slower).  The launch shapes used by
+    default (8 waves x 1 tile for dim <= 512, 4 waves x 1 tile for dim 768) must stay spill-free."""
+    from vectorlite_amd import build as vbuild
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "mfma.s")
+        cmd = [vbuild.hipcc(), f"--offload-arch={vbuild.ARCH}"] + vbuild.COMMON + [
+            "--cuda-device-only", "-S", os.path.join(vbuild.CSRC, "mfma_scan.hip"), "-o", out]
+        subprocess.run(cmd, check=True, capture_output=True)
+        asm = open(out).read()
+    seen = 0
+    for block in asm.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        m = re.search(r"k_mfma_scanILi(\d+)ELi(\d)ELi(\d)ELi(\d)ELi(\d)E", name)
+        if not m:
+            continue
+        ksteps, mode, metric, nw, qt = map(int, m.groups())
+        default = (ksteps < 48 and (nw, qt) == (8, 1)) or (ksteps >= 48 and (nw, qt) == (4, 1))
+        if not default:
+            continue
+        seen += 1
+        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1))
+        assert scratch <= 128, (name, scratch)
+        assert "v_mfma_f32_32x32x16_bf16" in asm
+    assert seen >= 24

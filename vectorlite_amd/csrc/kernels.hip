@@ -304,30 +304,55 @@ __device__ __forceinline__ void rescore_rows(const double* __restrict__ master, 
                                              uint32_t dim, const uint32_t* sh_pos, int n_rows,
                                              double (*tile)[RESCORE_CH + 1], double* qtile, Acc64<METRIC>& A)
 {
+    // PF chunks of 96 columns are fetched from HBM together (one memory latency for 384 columns
+    // instead of four); they then pass through the LDS tile one after the other, in column order.
+    constexpr int PER = (KP * RESCORE_CH + NTHREADS - 1) / NTHREADS;  // tile elements per thread
+    constexpr int PF = (NTHREADS >= 1024) ? 4 : 1;
     const int tid = threadIdx.x;
     A.init();
-    for (uint32_t c0 = 0; c0 < dim; c0 += RESCORE_CH) {
-        const uint32_t cw = (dim - c0) < (uint32_t)RESCORE_CH ? (dim - c0) : (uint32_t)RESCORE_CH;
-        __syncthreads();  // previous chunk fully consumed
-        for (int idx = tid; idx < KP * RESCORE_CH; idx += NTHREADS) {
-            const int r = idx / RESCORE_CH, cc = idx % RESCORE_CH;
-            if (r < n_rows && (uint32_t)cc < cw) tile[r][cc] = master[(size_t)sh_pos[r] * dim + c0 + cc];
-        }
-        if (tid < RESCORE_CH && (uint32_t)tid < cw) qtile[tid] = q64[c0 + tid];
-        __syncthreads();
-        if (tid < n_rows) {
-            uint32_t cc = 0;
-            for (; cc + 8 <= cw; cc += 8) {  // 16 LDS reads in flight, then 8 steps in index order
-                double xv[8], yv[8];
+    for (uint32_t g0 = 0; g0 < dim; g0 += PF * RESCORE_CH) {
+        double pre[PF][PER];
+        double qpre[PF];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    xv[t] = tile[tid][cc + t];
-                    yv[t] = qtile[cc + t];
-                }
+        for (int p = 0; p < PF; ++p) {
+            const uint32_t c0 = g0 + p * RESCORE_CH;
 #pragma unroll
-                for (int t = 0; t < 8; ++t) A.step(xv[t], yv[t]);
+            for (int i = 0; i < PER; ++i) {
+                const int idx = tid + i * NTHREADS;
+                const int r = idx / RESCORE_CH, cc = idx % RESCORE_CH;
+                double v = 0.0;
+                if (idx < KP * RESCORE_CH && r < n_rows && c0 + cc < dim) v = master[(size_t)sh_pos[r] * dim + c0 + cc];
+                pre[p][i] = v;
             }
-            for (; cc < cw; ++cc) A.step(tile[tid][cc], qtile[cc]);
+            qpre[p] = (tid < RESCORE_CH && c0 + tid < dim) ? q64[c0 + tid] : 0.0;
+        }
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const uint32_t c0 = g0 + p * RESCORE_CH;
+            if (c0 >= dim) break;  // workgroup-uniform
+            const uint32_t cw = (dim - c0) < (uint32_t)RESCORE_CH ? (dim - c0) : (uint32_t)RESCORE_CH;
+            __syncthreads();  // previous chunk fully consumed
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int idx = tid + i * NTHREADS;
+                if (idx < KP * RESCORE_CH) tile[idx / RESCORE_CH][idx % RESCORE_CH] = pre[p][i];
+            }
+            if (tid < RESCORE_CH) qtile[tid] = qpre[p];
+            __syncthreads();
+            if (tid < n_rows) {
+                uint32_t cc = 0;
+                for (; cc + 8 <= cw; cc += 8) {  // 16 LDS reads in flight, then 8 steps in index order
+                    double xv[8], yv[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        xv[t] = tile[tid][cc + t];
+                        yv[t] = qtile[cc + t];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) A.step(xv[t], yv[t]);
+                }
+                for (; cc < cw; ++cc) A.step(tile[tid][cc], qtile[cc]);
+            }
         }
     }
 }

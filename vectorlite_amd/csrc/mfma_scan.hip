@@ -8,7 +8,7 @@
 //
 // bf16 scores are only a CANDIDATE FILTER.  The Q x N score matrix is never written:
 //   pass 0 (a 1/16 sample of the rows): every workgroup reports, per query, the best key of its
-//     contiguous row range; the 64th largest of those maxima is a valid lower bound T_q of the
+//     own set of row tiles; the 64th largest of those maxima is a valid lower bound T_q of the
 //     query's 64th best key (64 distinct rows reach it);
 //   pass 1 (all rows): keys >= T_q are appended to the query's candidate buffer (about 10^3 of 10^7);
 //   then per query: top-64 of the buffer -> the same finalize kernel as the f32 path: exact f64
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
                                                    const __bf16* __restrict__ q16, uint32_t nq, uint32_t n_tiles,
                                                    uint32_t n_rows, int* __restrict__ gmax, uint32_t n_groups,
                                                    const float* __restrict__ thr, Cand32* __restrict__ cand,
-                                                   uint32_t* __restrict__ cnt, uint32_t cap, uint32_t ablate)
+                                                   uint32_t* __restrict__ cnt, uint32_t cap)
 {
     constexpr int LDB = KSTEPS * 16;            // bf16 elements per row
     constexpr int ROW_BYTES = LDB * 2;
@@ -90,19 +90,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
             bfrag[qt][s] = *reinterpret_cast<const bf16x8*>(q16 + (size_t)q[qt] * LDB + 16 * s + 8 * half);
     }
 
-    // tile schedule: MODE 0 gives every workgroup ONE contiguous range (its maxima describe distinct
-    // rows); MODE 1 grid-strides so that all workgroups stream neighbouring tiles
-    uint32_t t, t_end, t_step;
-    if (MODE == 0) {
-        const uint32_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
-        t = blockIdx.x * per;
-        t_end = t + per < n_tiles ? t + per : n_tiles;
-        t_step = 1;
-    } else {
-        t = blockIdx.x;
-        t_end = n_tiles;
-        t_step = gridDim.x;
-    }
+    // tile schedule: workgroup x takes tiles x, x + gridDim.x, ... in both modes, so neighbouring
+    // workgroups stream neighbouring tiles.  In MODE 0 that residue class is the workgroup's "group":
+    // its maximum belongs to rows no other group holds.
+    uint32_t t = blockIdx.x;
+    const uint32_t t_end = n_tiles, t_step = gridDim.x;
 
     float thr_q[QT], run_max[QT];
 #pragma unroll
@@ -194,7 +186,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
     };
     // hipcc drains the ring (vmcnt(0)) at the loop header but uses counted waits inside straight-line
     // code, so one trip covers UNROLL * DEPTH tiles: one drain per 16 tiles instead of one per 4.
-    constexpr int UNROLL = 4;
+    constexpr int UNROLL = (MODE == 0) ? 1 : 4;  // the sampling pass is 1/16 of the work: keep it small
     for (uint32_t base = t; base < t_end; base += UNROLL * DEPTH * t_step) {
 #pragma unroll
         for (int jj2 = 0; jj2 < UNROLL * DEPTH; ++jj2) {
@@ -224,7 +216,6 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
             constexpr int NG = KSTEPS / GS;
             static_assert(KSTEPS % GS == 0, "K steps come in whole groups");
             bf16x8 afrag[2][GS];
-            if (!(ablate & 2u)) {
 #pragma unroll
             for (int jj = 0; jj < GS; ++jj) afrag[0][jj] = *reinterpret_cast<const bf16x8*>(arow + jj * 32);
 #pragma unroll
@@ -243,23 +234,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
                                                                           acc[qt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            }  // ablate & 2
             // C layout: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5):
             // registers 4g..4g+3 are the four consecutive rows 8g + 4*half + {0..3}.
             // Epilogue on the common path = 16 multiplies, a max tree and ONE compare against the
             // query's threshold; the per-row work only runs for the rare tile that holds a candidate.
             const uint32_t row0 = tile * MF_ROWS;
-            if (ablate & 1u) {
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                    asm volatile("" ::"v"(acc[qt]));  // keep the MFMA results live
-#endif
-                }
-                if (NBUF == 1) __syncthreads();
-                buf = (NBUF == 2) ? (buf ^ 1) : 0;
-                continue;
-            }
             f32x4 aux[4], aux2[4];
             if (METRIC != COSINE) {
 #pragma unroll
@@ -309,6 +288,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
             }
             if (NBUF == 1) __syncthreads();  // single buffer: everyone is done reading before the next write
             buf = (NBUF == 2) ? (buf ^ 1) : 0;
+            // one scheduling region per tile: across the 16 unrolled tiles the scheduler otherwise
+            // hoists the epilogues' LDS reads and spills hundreds of registers (MODE 0 has no branch
+            // in its epilogue to stop it)
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (MODE == 1) {
             __syncthreads();
@@ -510,17 +493,15 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     const int pass1_blocks = (int)std::min<uint32_t>(n_tiles, (uint32_t)env_grid(n_chunks));
     const dim3 grid1(pass1_blocks, nq_pad / qpb);
 
-    const char* abl = getenv("VL_MFMA_ABLATE");
-    const uint32_t ablate = abl && *abl ? (uint32_t)atoi(abl) : 0u;  // diagnostics only: 1 = no epilogue, 2 = no MFMA
     bool launched = false;
 #define VL_LAUNCH3(K, MET, NW, QTT)                                                                                     \
     {                                                                                                                   \
         hipLaunchKernelGGL((k_mfma_scan<K, 0, MET, NW, QTT>), grid0, dim3(NW * 64), 0, s, slab, row_norm, row_sqnorm, q16, nq,       \
                            sample_tiles, (uint32_t)sample_rows, w.gmax, n_groups, (const float*)nullptr,               \
-                           (Cand32*)nullptr, (uint32_t*)nullptr, 0u, 0u);                                               \
+                           (Cand32*)nullptr, (uint32_t*)nullptr, 0u);                                                   \
         hipLaunchKernelGGL(k_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.gmax, n_groups, nq, w.thr);             \
         hipLaunchKernelGGL((k_mfma_scan<K, 1, MET, NW, QTT>), grid1, dim3(NW * 64), 0, s, slab, row_norm, row_sqnorm, q16, nq,       \
-                           n_tiles, (uint32_t)n_rows, (int*)nullptr, 0u, w.thr, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, ablate); \
+                           n_tiles, (uint32_t)n_rows, (int*)nullptr, 0u, w.thr, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP); \
         launched = true;                                                                                                \
     }
 #define VL_LAUNCH2(K, MET)                                        \
