@@ -105,7 +105,7 @@ def test_random_parity_all_metrics(V, O, dim):
         for qi in range(3):
             q = unit_rows(rng, 1, dim)[0]
             for name, m in M.items():
-                for k in (1, 10, 32):
+                for k in (1, 10, 32, 48, 49):
                     assert_same(V, gpu.search_arrays(q, k, m), ref.search(q, k, m), (dim, n, name, k))
 
 
@@ -329,7 +329,7 @@ def test_batch_scan_kernel_parity(V, O, dim):
     """k_scan_batch (8 queries per slab pass) vs the oracle, including queries that must fall back:
     duplicates at the cut, an out-of-domain query, a zero query; dim = 100 has no batch shape."""
     rng = np.random.default_rng(100 + dim)
-    n, nq = 6000, 21
+    n, nq = 6000, 7   # 7 queries: the f32 batch kernel (8 and more take the bf16 MFMA filter)
     rows = unit_rows(rng, n, dim)
     rows[4000:4040] = rows[17]  # 41 identical rows: a tie group wider than any k below
     ids = permuted_ids(n)
@@ -339,9 +339,9 @@ def test_batch_scan_kernel_parity(V, O, dim):
     Q = unit_rows(rng, nq, dim)
     Q[3] = rows[17]       # hits the tie group -> exact fallback for this query only
     Q[5] = Q[5] * 1e100   # out of the f32 domain
-    Q[9] = 0.0            # zero query
+    Q[6] = 0.0            # zero query
     for name, m in M.items():
-        for k in (1, 10, 32):
+        for k in (1, 10, 32, 48):
             bi, bs, bn = gpu.search_batch(Q, k, m)
             pos, pid, psc, pn = gpu.search_batch_positions(Q, k, m)
             for i in range(nq):
@@ -372,7 +372,7 @@ def test_mfma_large_batch_parity(V, O, dim, n):
     Q[11] = rows[500] * 0.999 + Q[11] * 0.001
     for name in ("cosine", "dotproduct", "euclidean"):
         m = M[name]
-        for k in (1, 10, 32):
+        for k in (1, 10, 32, 48):
             bi, bs, bn = gpu.search_batch(Q, k, m)
             for i in range(nq):
                 ri, rs = ref.search(Q[i], k, m)

@@ -27,6 +27,7 @@ def main():
     Q = rng.standard_normal((a.nq, a.dim)); Q /= np.linalg.norm(Q, axis=1, keepdims=True)
     idx.search_batch(Q[:16], 10, a.metric)
     idx.search_batch(Q[:min(a.nq, 128)], 10, a.metric)
+    idx.search_batch(Q, 10, a.metric)
     idx.profile_read(); idx.profile_enable(True)
     t0 = time.perf_counter(); bi, bs, bn = idx.search_batch(Q, 10, a.metric); tb = time.perf_counter() - t0
     n, ms, b = idx.profile_read()

@@ -501,7 +501,9 @@ int GpuFlatIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_le
     std::vector<uint8_t> done(nq, 0);
     const char* mf_env = getenv("VL_MFMA");
     const bool mfma_on = !(mf_env && mf_env[0] == '0');
-    if (mfma_on && nq >= (uint64_t)MFMA_MIN_BATCH && mfma_scan_supported((uint32_t)dim_, metric)) {
+    const char* mf_min = getenv("VL_MFMA_MIN_BATCH");
+    const uint64_t mfma_min = mf_min && *mf_min ? (uint64_t)atoi(mf_min) : (uint64_t)MFMA_MIN_BATCH;
+    if (mfma_on && nq >= mfma_min && mfma_scan_supported((uint32_t)dim_, metric)) {
         VL_TRY(search_batch_mfma(ws, queries, nq, k, k_eff, metric, out_pos, out_ids, out_scores, out_n, &done));
         uint64_t left = 0;
         for (uint64_t qi = 0; qi < nq; ++qi) left += done[qi] ? 0 : 1;
