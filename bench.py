@@ -48,7 +48,7 @@ def parse_args():
     p.add_argument("--metric", default="cosine", choices=["cosine", "euclidean", "manhattan", "dotproduct"])
     p.add_argument("--chunk", type=int, default=500_000, help="rows generated per device chunk")
     p.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
-    p.add_argument("--cpu-queries", type=int, default=16)
+    p.add_argument("--cpu-queries", type=int, default=32)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-checks", action="store_true")
     return p.parse_args()
@@ -79,8 +79,11 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from vectorlite_amd import build as vbuild
-    if not os.path.exists(vbuild.SO):
-        vbuild.build()
+    if not os.path.exists(vbuild.SO):  # normally prebuilt by __graft_entry__.build(); never build concurrently
+        if rank == 0:
+            vbuild.build()
+        if world > 1:
+            dist.barrier()
     import vectorlite_amd as V
 
     metric = {"cosine": 0, "euclidean": 1, "manhattan": 2, "dotproduct": 3}[args.metric]
