@@ -207,6 +207,34 @@ def main():
         },
     }
 
+    # ---- informational: the opt-in bf16-first filter (NOT the headline: north_star's slab is f32) ----
+    if not args.no_checks:
+        idx.set_single_filter("bf16")
+        for i in range(10):
+            idx.search_arrays(Q[i], k, metric)
+        idx.profile_read()
+        idx.profile_enable(True)
+        nb = max(10, args.steps // 4)
+        same = 0
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        outs = [idx.search_arrays(Q[args.warmup + i], k, metric) for i in range(nb)]
+        torch.cuda.synchronize()
+        tb = time.perf_counter() - tb
+        idx.profile_enable(False)
+        nl, ms16, by16 = idx.profile_read()
+        idx.set_single_filter("f32")
+        for i in range(min(nb, 8)):
+            fi, fs = idx.search_arrays(Q[args.warmup + i], k, metric)
+            same += int(fi.tolist() == outs[i][0].tolist() and fs.tolist() == outs[i][1].tolist())
+        out["config"]["bf16_first_filter_optin"] = {
+            "qps": round(nb / tb, 1), "ms_per_step": round(tb / nb * 1e3, 4),
+            "scan_GBps_on_bf16_bytes": round(by16 / max(nl, 1) / (ms16 / max(nl, 1) * 1e-3) / 1e9, 1) if nl else None,
+            "identical_to_f32_path": f"{same}/{min(nb, 8)} queries (ids and f64 scores)",
+            "note": "vl_index_set_single_filter(h, 1): scan a bf16 copy of the slab first, same exact f64 "
+                    "rescoring and bound check, fall back to the f32 scan when not certified",
+        }
+
     # ---- correctness properties at full size ----------------------------------------------------
     if not args.no_checks:
         n_chk = 4

@@ -178,6 +178,11 @@ int vl_last_path(void);                                          /* vl_path of t
 /* Force every search onto an exact pipeline (testing): 0 = automatic, 2 / 3 = vl_path value. */
 int vl_index_force_path(vl_index *h, int path);
 
+/* Single-query candidate filter: 0 = stream the f32 slab (default, north_star's layout);
+ * 1 = stream a bf16 copy of the slab first (half the HBM bytes) and fall back to the f32 scan when
+ * the exactness bound cannot certify the answer.  Results are identical either way. */
+int vl_index_set_single_filter(vl_index *h, int mode);
+
 /* Kernel timing with HIP events on the stream the scan kernel runs on.
  * enable != 0 starts accumulating; vl_index_profile_read returns and clears the totals. */
 int vl_index_profile_enable(vl_index *h, int enable);

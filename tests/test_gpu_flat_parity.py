@@ -577,3 +577,26 @@ def test_bound_check_survives_random_scales(V, O):
         q = rng.standard_normal(dim) * 10.0 ** rng.uniform(-6, 6)
         for name, m in M.items():
             assert_same(V, gpu.search_arrays(q, 10, m), ref.search(q, 10, m), (trial, name))
+
+
+@pytest.mark.parametrize("dim", [128, 384, 768])
+def test_bf16_single_query_filter_is_exact(V, O, dim):
+    """Opt-in first stage on the bf16 slab: same ids and scores as the oracle, on easy queries
+    (certified by the bf16 bound) and on near-ties (handed on to the f32 scan / exact kernels)."""
+    rng = np.random.default_rng(dim)
+    n = 20000
+    rows = unit_rows(rng, n, dim)
+    rows[5000:5030] = rows[9] + 1e-4 * rng.standard_normal((30, dim))  # closer than bf16 can resolve
+    ids = permuted_ids(n)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows, validate=False)
+    gpu.set_single_filter("bf16")
+    ref = O.FlatOracle(dim, ids, rows)
+    for qi in range(10):
+        q = rows[9] if qi == 0 else unit_rows(rng, 1, dim)[0]
+        for name, m in M.items():
+            for k in (1, 10, 40):
+                assert_same(V, gpu.search_arrays(q, k, m), ref.search(q, k, m), (dim, qi, name, k))
+    gpu.add(V.Vector(10 ** 12, rows[3] * 1.0000001))
+    ref.add(10 ** 12, rows[3] * 1.0000001)
+    assert_same(V, gpu.search_arrays(rows[3], 5, 0), ref.search(rows[3], 5, 0), "after add")

@@ -346,6 +346,10 @@ class FlatIndex:
     def force_path(self, path: int) -> None:
         _raise(self._L.vl_index_force_path(self._h, int(path)))
 
+    def set_single_filter(self, mode: str) -> None:
+        """"f32" (default) or "bf16": which copy of the slab single queries scan first."""
+        _raise(self._L.vl_index_set_single_filter(self._h, {"f32": 0, "bf16": 1}[mode]))
+
     def profile_enable(self, on: bool) -> None:
         _raise(self._L.vl_index_profile_enable(self._h, 1 if on else 0))
 

@@ -294,6 +294,13 @@ int vl_index_force_path(vl_index* h, int path)
     return VL_OK;
 }
 
+int vl_index_set_single_filter(vl_index* h, int mode)
+{
+    if (!h || !h->flat || (mode != 0 && mode != 1)) return VL_ERR_INVALID_ARG;
+    h->flat->set_single_filter(mode);
+    return VL_OK;
+}
+
 int vl_index_profile_enable(vl_index* h, int enable)
 {
     if (!h || !h->flat) return VL_ERR_INVALID_ARG;

@@ -125,6 +125,9 @@ int GpuFlatIndex::create(uint64_t dim, int device, GpuFlatIndex** out)
     VL_TRY(dev_alloc(&idx->d_stats_, 1));
     VL_HIP(hipMemsetAsync(idx->d_stats_, 0, sizeof(IngestStats), idx->mut_stream_));
     VL_HIP(hipStreamSynchronize(idx->mut_stream_));
+    if (const char* sf = getenv("VL_SINGLE_FILTER")) {
+        if (std::strcmp(sf, "bf16") == 0) idx->set_single_filter(1);
+    }
     *out = idx.release();
     return OK;
 }
@@ -616,6 +619,51 @@ int GpuFlatIndex::search_locked(Workspace* ws, const double* query, uint64_t k_e
     const int forced = force_path_.load();
     const bool fast_ok = !skip_fast && forced == 0 && k_eff <= (uint64_t)KFAST_MAX && n_out_of_domain_ == 0 &&
                          q_in_domain;
+
+    // Opt-in first stage: scan the bf16 copy of the slab (half the HBM bytes).  Its candidates get the
+    // same exact f64 rescoring and a bound with the bf16 row-rounding term; if that cannot certify
+    // the answer the f32 scan below runs as before.  The stage switches itself off on data where it
+    // rarely certifies (dense neighbourhoods).
+    if (fast_ok && single_filter_.load() == 1 && scan_bf16_supported((uint32_t)dim_, metric) &&
+        !(bf16_tries_.load() >= 64 && bf16_fails_.load() * 3 > bf16_tries_.load())) {
+        VL_TRY(ensure_bf16_slab());
+        const bool prof = profile_.load();
+        int grid = 0;
+        if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
+        VL_HIP(launch_scan_bf16(st, metric, d_slab16_, d_norm16_, d_sqnorm_, ws->d_q64, n, (uint32_t)dim_,
+                                ws->d_partials, &grid));
+        if (prof) VL_HIP(hipEventRecord(ws->ev1, st));
+        // rows are rounded to bf16 (relative 2^-8 after the f32 step), the query is f32: u_b (1 + u) + u
+        VL_HIP(launch_merge_finalize(st, metric, ws->d_partials, grid, 1, d_master_, ws->d_q64, ws->d_q64 + dim_,
+                                     (uint32_t)dim_, n, (uint32_t)k_eff, max_row_norm_, ws->h_result, 0.00392));
+        VL_HIP(hipStreamSynchronize(st));
+        if (prof) {
+            float ms = 0.f;
+            VL_HIP(hipEventElapsedTime(&ms, ws->ev0, ws->ev1));
+            std::lock_guard<std::mutex> g(prof_mu_);
+            prof_n_ += 1;
+            prof_ms_ += ms;
+            prof_bytes_ += n * (uint64_t)mfma_ldb((uint32_t)dim_) * 2;
+        }
+        bf16_tries_.fetch_add(1);
+        const SearchResultBlock& r = *ws->h_result;
+        if (!(r.flags & RESULT_NEEDS_EXACT) && r.n_out == k_eff) {
+            for (uint64_t i = 0; i < k_eff; ++i) {
+                const uint32_t p = r.pos[i];
+                if (p >= n) {
+                    set_last_error("bf16 filter returned an out-of-range position (kernel bug)");
+                    return ERR_DEVICE;
+                }
+                if (out_pos) out_pos[i] = p;
+                if (out_ids) out_ids[i] = ids_[p];
+                out_scores[i] = r.score[i];
+            }
+            *out_n = k_eff;
+            set_last_path(PATH_FAST);
+            return OK;
+        }
+        bf16_fails_.fetch_add(1);
+    }
     if (fast_ok) {
         const bool prof = profile_.load();
         ScanPlan plan;

@@ -115,6 +115,13 @@ public:
     uint64_t capacity() const { return cap_; }
 
     void force_path(int p) { force_path_.store(p); }
+    // 0: single queries scan the f32 slab (default); 1: try the bf16 slab first (half the bytes)
+    void set_single_filter(int mode)
+    {
+        single_filter_.store(mode);
+        bf16_tries_.store(0);
+        bf16_fails_.store(0);
+    }
     void profile_enable(bool on);
     void profile_read(uint64_t* n, double* ms, uint64_t* bytes);
     int device() const { return device_; }
@@ -173,6 +180,8 @@ private:
     mutable std::vector<std::unique_ptr<Workspace>> ws_all_;
 
     std::atomic<int> force_path_{0};
+    std::atomic<int> single_filter_{0};
+    mutable std::atomic<uint64_t> bf16_tries_{0}, bf16_fails_{0};
     std::atomic<bool> profile_{false};
     mutable std::mutex prof_mu_;
     mutable uint64_t prof_n_ = 0;

@@ -309,6 +309,87 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Single-query scan of the bf16 slab (opt-in candidate filter: half the HBM bytes of the f32 scan).
+// Same structure as k_scan (kernels.hip): G lanes share a row, 16-byte non-temporal loads straight to
+// registers (8 bf16 each), shuffle reduction, one sorted top-64 list per wave.  The query stays f32
+// (only the rows carry bf16 rounding), bf16 -> f32 is a shift, the products accumulate with fmaf.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot8_bf16(float a, const u32x4 x, const f32x4 q0, const f32x4 q1)
+{
+    a = fmaf(__uint_as_float(x.x << 16), q0.x, a);
+    a = fmaf(__uint_as_float(x.x & 0xFFFF0000u), q0.y, a);
+    a = fmaf(__uint_as_float(x.y << 16), q0.z, a);
+    a = fmaf(__uint_as_float(x.y & 0xFFFF0000u), q0.w, a);
+    a = fmaf(__uint_as_float(x.z << 16), q1.x, a);
+    a = fmaf(__uint_as_float(x.z & 0xFFFF0000u), q1.y, a);
+    a = fmaf(__uint_as_float(x.w << 16), q1.z, a);
+    a = fmaf(__uint_as_float(x.w & 0xFFFF0000u), q1.w, a);
+    return a;
+}
+
+template <int METRIC, int G, int VPL>
+__global__ __launch_bounds__(256) void k_scan_bf16(const u32x4* __restrict__ slab16, const float* __restrict__ row_nrm,
+                                                   const float* __restrict__ row_sqn,
+                                                   const double* __restrict__ q64, uint32_t dim, uint32_t n,
+                                                   Cand32* __restrict__ out)
+{
+    constexpr int RPS = WAVE / G;
+    constexpr uint32_t LD8 = G * VPL;  // 16-byte chunks (8 bf16) per row
+    __shared__ Cand32 sh[4 * WAVE];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int g = lane / G, c = lane % G;
+
+    f32x4 qv[VPL][2];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const uint32_t e0 = 8u * (uint32_t)(c + G * j);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 v;
+            v.x = e0 + 4 * h + 0 < dim ? (float)q64[e0 + 4 * h + 0] : 0.0f;
+            v.y = e0 + 4 * h + 1 < dim ? (float)q64[e0 + 4 * h + 1] : 0.0f;
+            v.z = e0 + 4 * h + 2 < dim ? (float)q64[e0 + 4 * h + 2] : 0.0f;
+            v.w = e0 + 4 * h + 3 < dim ? (float)q64[e0 + 4 * h + 3] : 0.0f;
+            qv[j][h] = v;
+        }
+    }
+    const uint32_t n_steps = (n + RPS - 1) / RPS;
+    const uint32_t n_waves = gridDim.x * 4;
+    TopList<float> L;
+    L.init();
+    for (uint32_t s = blockIdx.x * 4 + wave; s < n_steps; s += n_waves) {
+        const uint32_t row = s * RPS + g;
+        const bool valid = row < n;
+        const uint32_t r = valid ? row : n - 1;
+        const u32x4* p = slab16 + (size_t)r * LD8 + c;
+        u32x4 x[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) x[j] = __builtin_nontemporal_load(p + G * j);
+        float nr = 1.0f, sq = 0.0f;
+        if (METRIC != COSINE) nr = row_nrm[r];
+        if (METRIC == EUCLIDEAN) sq = row_sqn[r];
+        __builtin_amdgcn_sched_barrier(0);
+        float a = 0.0f;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) a = dot8_bf16(a, x[j], qv[j][0], qv[j][1]);
+#pragma unroll
+        for (int o = G / 2; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+        float key = a;                                            // cosine: x^.q
+        if (METRIC == DOT) key = a * nr;                          // x.q
+        if (METRIC == EUCLIDEAN) key = 2.0f * a * nr - sq;        // |q|^2 - |x - q|^2
+        L.offer(key, row, valid && c == 0);
+    }
+    block_merge<float, Cand32, 4>(L, sh);
+    if (wave == 0) {
+        Cand32 e;
+        e.key = L.key;
+        e.pos = L.pos;
+        out[(size_t)blockIdx.x * KP + lane] = e;
+    }
+}
+
 // T_q = the 64th largest group maximum (a lower bound of the query's 64th best key); -inf when fewer
 // than 64 groups exist.  One wave per query.
 __global__ __launch_bounds__(256) void k_thresholds(const int* __restrict__ gmax, uint32_t n_groups, uint32_t nq,
@@ -522,6 +603,58 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
 #undef VL_LAUNCH3
     if (!launched) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_select_candidates, dim3(nq), dim3(256), 0, s, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, out_lists);
+    return hipGetLastError();
+}
+
+#define VL_BF16_SCAN_SHAPES(X) X(8, 2) X(8, 4) X(8, 6) X(8, 8) X(16, 6)
+
+bool scan_bf16_supported(uint32_t dim, int metric)
+{
+    if (metric != COSINE && metric != DOT && metric != EUCLIDEAN) return false;
+    const uint32_t ld8 = mfma_ldb(dim) / 8;
+    bool ok = false;
+#define VL_CHK(G, VPL) ok = ok || (ld8 == (uint32_t)(G * VPL));
+    VL_BF16_SCAN_SHAPES(VL_CHK)
+#undef VL_CHK
+    return ok;
+}
+
+hipError_t launch_scan_bf16(hipStream_t s, int metric, const void* slab_bf16, const float* row_norm,
+                            const float* row_sqnorm, const double* q64, uint64_t n, uint32_t dim, Cand32* partials,
+                            int* grid_out)
+{
+    if (n == 0 || n >= 0xFFFFFFFFull || !scan_bf16_supported(dim, metric)) return hipErrorInvalidValue;
+    const uint32_t ld8 = mfma_ldb(dim) / 8;
+    const u32x4* slab = reinterpret_cast<const u32x4*>(slab_bf16);
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const char* ge = getenv("VL_SCAN16_BPC");
+    const int bpc = ge && *ge ? atoi(ge) : 3;  // measured: 2-3 workgroups per CU stream fastest (like k_scan)
+    bool launched = false;
+    int grid = 1;
+#define VL_L3(MET, G, VPL)                                                                                     \
+    {                                                                                                          \
+        const uint64_t steps = (n + (64 / G) - 1) / (64 / G);                                                  \
+        uint64_t blocks = (steps + 3) / 4;                                                                     \
+        if (blocks > (uint64_t)(cus * bpc)) blocks = (uint64_t)(cus * bpc);                                    \
+        if (blocks > (uint64_t)SCAN_MAX_GRID) blocks = SCAN_MAX_GRID;                                          \
+        grid = (int)(blocks < 1 ? 1 : blocks);                                                                 \
+        hipLaunchKernelGGL((k_scan_bf16<MET, G, VPL>), dim3(grid), dim3(256), 0, s, slab, row_norm, row_sqnorm, \
+                           q64, dim, (uint32_t)n, partials);                                                   \
+        launched = true;                                                                                       \
+    }
+#define VL_L(G, VPL)                                               \
+    if (!launched && ld8 == (uint32_t)(G * VPL)) {                 \
+        if (metric == COSINE) VL_L3(COSINE, G, VPL)                \
+        else if (metric == EUCLIDEAN) VL_L3(EUCLIDEAN, G, VPL)     \
+        else VL_L3(DOT, G, VPL)                                    \
+    }
+    VL_BF16_SCAN_SHAPES(VL_L)
+#undef VL_L
+#undef VL_L3
+    if (!launched) return hipErrorInvalidValue;
+    if (grid_out) *grid_out = grid;
     return hipGetLastError();
 }
 

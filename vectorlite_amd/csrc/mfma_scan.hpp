@@ -43,4 +43,10 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
                                   const double* q64, uint32_t nq, uint64_t n_rows, uint32_t dim,
                                   const MfmaScratch& w, Cand32* out_lists);
 
+// Single-query scan of the bf16 slab (opt-in filter): per-workgroup top-64 lists like launch_scan.
+bool scan_bf16_supported(uint32_t dim, int metric);
+hipError_t launch_scan_bf16(hipStream_t s, int metric, const void* slab_bf16, const float* row_norm,
+                            const float* row_sqnorm, const double* q64, uint64_t n, uint32_t dim, Cand32* partials,
+                            int* grid_out);
+
 }  // namespace vl
