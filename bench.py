@@ -61,6 +61,102 @@ def ids_for(start: int, n: int) -> np.ndarray:
     return pos * np.uint64(2654435761) + np.uint64(97)
 
 
+def host_cores() -> int:
+    """CPUs this process may actually use: affinity mask capped by the cgroup quota (cpu.max)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except Exception:
+            pass
+    return n
+
+
+def fair_cpu_baseline(rows64, queries, k, n_full, exact_ids, ids):
+    """SURVEY 8(d) mode (ii): contiguous f32 slab + cached norms + OpenMP over every host core
+    (oracle/vl_fair.c, built here with -march=native).  Reported beside cpu_baseline, never instead of it."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    try:
+        so = os.path.join(tempfile.mkdtemp(prefix="vl_fair_"), "libvl_fair.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-shared", "-fPIC", "-o", so,
+                               os.path.join(ROOT, "oracle", "vl_fair.c"), "-lm"])
+        L = C.CDLL(so)
+    except Exception as e:  # no compiler on the box: say so instead of inventing a number
+        return {"value": None, "note": f"oracle/vl_fair.c could not be built here: {e}"}
+    fp, u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+    L.vlf_search_cosine.restype = C.c_size_t
+    L.vlf_search_cosine.argtypes = [fp, fp, C.c_size_t, C.c_size_t, fp, C.c_size_t, u32p, fp]
+    L.vlf_inv_norms.argtypes = [fp, C.c_size_t, C.c_size_t, fp]
+    L.vlf_threads.restype = C.c_int
+    slab = np.ascontiguousarray(rows64, dtype=np.float32)
+    ns, dim = slab.shape
+    inv = np.empty(ns, np.float32)
+    L.vlf_inv_norms(slab.ctypes.data_as(fp), ns, dim, inv.ctypes.data_as(fp))
+    q32 = np.ascontiguousarray(queries, dtype=np.float32)
+    pos, sc = np.empty(k, np.uint32), np.empty(k, np.float32)
+
+    def one(i):
+        g = L.vlf_search_cosine(slab.ctypes.data_as(fp), inv.ctypes.data_as(fp), ns, dim, q32[i].ctypes.data_as(fp), k,
+                                pos.ctypes.data_as(u32p), sc.ctypes.data_as(fp))
+        return ids[pos[:g]].tolist()
+    # thread count: the CPU share may be smaller than the visible core count; keep the fastest
+    best = (None, 0)
+    nc = host_cores()
+    for nt in sorted({nc, max(1, nc // 2), max(1, nc // 4), min(nc, 16)}):
+        L.vlf_set_threads(nt)
+        one(0)  # threads up, pages touched
+        t = time.perf_counter()
+        one(0)
+        one(1 % len(q32))
+        t = time.perf_counter() - t
+        if best[0] is None or t < best[0]:
+            best = (t, nt)
+    L.vlf_set_threads(best[1])
+    one(0)
+    reps = 4
+    t = time.perf_counter()
+    got = [one(i) for _ in range(reps) for i in range(len(q32))][-len(q32):]
+    t = time.perf_counter() - t
+    qps_s = reps * len(q32) / t
+    hits = sum(len(set(a) & set(b.tolist())) for a, b in zip(got, exact_ids))
+    return {
+        "value": round(qps_s * ns / n_full, 4), "unit": "queries/s", "cores": int(L.vlf_threads()), "kind": "fair-cpu",
+        "scan_GBps": round(ns * dim * 4 * qps_s / 1e9, 1),
+        "recall_at_k_vs_oracle": round(hits / float(len(q32) * min(k, ns)), 6),
+        "sample": (f"{reps}x{len(q32)} cosine queries on the first {ns} rows as a contiguous f32 slab with cached norms, "
+                   f"per-thread top-k, OpenMP on {int(L.vlf_threads())} threads (oracle/vl_fair.c, gcc -O3 -march=native); "
+                   f"{t:.1f}s wall; {qps_s:.2f} q/s at N={ns}, scaled x{ns / n_full:g}; f32 scores, not the reference's f64"),
+    }
+
+
+def device_copy_ceiling(torch, dev, nbytes=4 << 30, reps=10):
+    """Measured device-to-device copy rate (read + write bytes / time): the practical HBM ceiling
+    SURVEY 8(d) asks to be reported beside the 8 TB/s vendor peak."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del a, b
+    torch.cuda.empty_cache()
+    return round(2 * nbytes / (ms * 1e-3) / 1e9, 1)
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -72,11 +168,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # VL_BENCH_REHEARSE=1 (one-GPU rehearsal of the multi-rank path): ranks share the visible cards and
+    # rendezvous over gloo, because RCCL refuses two ranks on one device.  Never set by the driver.
+    rehearse = os.environ.get("VL_BENCH_REHEARSE") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from vectorlite_amd import build as vbuild
     if not os.path.exists(vbuild.SO):  # normally prebuilt by __graft_entry__.build(); never build concurrently
@@ -91,7 +194,7 @@ def main():
 
     # ---- build the replica: rows generated on the device, ingested device-to-device -------------
     t0 = time.time()
-    idx = V.FlatIndex(dim, device=local_rank)
+    idx = V.FlatIndex(dim, device=dev_index)
     idx.reserve(n)
     sample_rows = None
     want_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)
@@ -147,7 +250,7 @@ def main():
     idx.profile_enable(False)
     n_launch, scan_ms, scan_bytes = idx.profile_read()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t.item())
@@ -208,7 +311,9 @@ def main():
     }
 
     # ---- informational: the opt-in bf16-first filter (NOT the headline: north_star's slab is f32) ----
-    if not args.no_checks:
+    extras = world == 1 and not args.no_checks  # N>1: every rank leaves together, nothing runs on rank 0 alone
+    if extras:
+        out["roofline"]["measured_d2d_copy_GBps"] = device_copy_ceiling(torch, dev)
         idx.set_single_filter("bf16")
         for i in range(10):
             idx.search_arrays(Q[i], k, metric)
@@ -236,7 +341,7 @@ def main():
         }
 
     # ---- correctness properties at full size ----------------------------------------------------
-    if not args.no_checks:
+    if extras:
         n_chk = 4
         agree = 0
         idx2_paths = set()
@@ -255,7 +360,7 @@ def main():
         O.build()
         ns = sample_rows.shape[0]
         ref = O.FlatOracle(dim, ids_for(0, ns), sample_rows)
-        sub = V.FlatIndex(dim, device=local_rank)
+        sub = V.FlatIndex(dim, device=dev_index)
         sub.add_rows(ids_for(0, ns), sample_rows, validate=False)
         nqc = args.cpu_queries
         tc = time.perf_counter()
@@ -283,6 +388,8 @@ def main():
                        f"{cpu_s:.1f}s CPU; measured {cpu_qps_sample:.3f} q/s at N={ns}, scaled x{scale:g} "
                        f"to N={n} (the scan is linear in N)"),
         }
+        if args.metric == "cosine":
+            out["cpu_baseline_fair"] = fair_cpu_baseline(sample_rows, Q[:nqc], k, n, [r[0] for r in ref_out], ids_for(0, ns))
         out["parity"] = {
             "checked_queries": nqc,
             "rows": ns,
