@@ -183,6 +183,16 @@ int vl_index_force_path(vl_index *h, int path);
  * the exactness bound cannot certify the answer.  Results are identical either way. */
 int vl_index_set_single_filter(vl_index *h, int mode);
 
+/* Coalescing of concurrent vl_index_search calls on a flat index (the reference serves searches
+ * concurrently under RwLock::read, src/client.rs:398; src/server.rs:269 -- one full scan each).
+ * max_batch >= 2: callers that arrive while a scan is in flight are answered together by the next
+ * slab pass (at most max_batch per pass; vl_index_search_batch's kernels); each caller still gets
+ * exactly the result and status a lone vl_index_search returns.  window_us > 0 additionally lets a
+ * lone caller wait that long for company.  max_batch 0/1 = off (default).
+ * vl_index_coalesce_stats: passes run and queries answered by them since creation. */
+int vl_index_set_coalescing(vl_index *h, int max_batch, int window_us);
+int vl_index_coalesce_stats(const vl_index *h, uint64_t *batches, uint64_t *queries);
+
 /* Kernel timing with HIP events on the stream the scan kernel runs on.
  * enable != 0 starts accumulating; vl_index_profile_read returns and clears the totals. */
 int vl_index_profile_enable(vl_index *h, int enable);

@@ -490,6 +490,63 @@ def test_concurrent_searches_from_many_threads(V, O):
     assert errors == []
 
 
+def test_coalesced_concurrent_searches_match_lone_searches(V, O):
+    """vl_index_set_coalescing: callers arriving together share slab passes (f32 batch kernel for 2-7,
+    bf16 MFMA filter for >= 8) and still get exactly the lone-search answer; mixed metrics / k values
+    split into separate passes; a NaN query fails alone (src/index/flat.rs:116 panics that search only)."""
+    import threading
+    rng = np.random.default_rng(78)
+    n, dim = 60000, 128
+    rows = unit_rows(rng, n, dim)
+    ids = permuted_ids(n)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    nq = 96
+    Q = unit_rows(rng, nq, dim)
+    spec = [(0, 10) if i % 3 else ((i // 3) % 4, 5 + (i % 2) * 5) for i in range(nq)]  # mostly (cosine, 10)
+    want = [ref.search(Q[i], k, m) for i, (m, k) in enumerate(spec)]
+    gpu.set_coalescing(64, 200)
+    errors = []
+    nan_seen = []
+    barrier = threading.Barrier(16)
+
+    def worker(t):
+        try:
+            barrier.wait()
+            for rep in range(2):
+                for i in range(t, nq, 16):
+                    m, k = spec[i]
+                    gi, gs = gpu.search_arrays(Q[i], k, m)
+                    if gi.tolist() != want[i][0].tolist() or gs.tolist() != want[i][1].tolist():
+                        errors.append((t, i))
+                if t == 3:
+                    bad = Q[0].copy()
+                    bad[5] = np.nan
+                    try:
+                        gpu.search_arrays(bad, 10, 0)
+                        errors.append((t, "NaN query did not fail"))
+                    except V.NaNScore:
+                        nan_seen.append(rep)
+        except Exception as e:  # pragma: no cover
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert errors == []
+    assert nan_seen == [0, 1]
+    batches, queries = gpu.coalesce_stats()
+    assert queries == 2 * nq + 2
+    assert batches < queries  # passes were shared
+    gpu.set_coalescing(0)
+    gi, gs = gpu.search_arrays(Q[1], 10, 0)
+    assert gi.tolist() == want[1][0].tolist()
+    assert gpu.coalesce_stats() == (batches, queries)
+
+
 def test_large_index_properties(V):
     """N = 2M x 128 (too big for the oracle in a test): fast path == exact path bit for bit,
     sortedness, idempotence, self-query returns the row itself with score 1, delete removes it."""

@@ -350,6 +350,15 @@ class FlatIndex:
         """"f32" (default) or "bf16": which copy of the slab single queries scan first."""
         _raise(self._L.vl_index_set_single_filter(self._h, {"f32": 0, "bf16": 1}[mode]))
 
+    def set_coalescing(self, max_batch: int, window_us: int = 0) -> None:
+        """Answer concurrent search() calls (other threads) with shared slab passes; 0 turns it off."""
+        _raise(self._L.vl_index_set_coalescing(self._h, int(max_batch), int(window_us)))
+
+    def coalesce_stats(self) -> Tuple[int, int]:
+        b, q = C.c_uint64(0), C.c_uint64(0)
+        _raise(self._L.vl_index_coalesce_stats(self._h, C.byref(b), C.byref(q)))
+        return int(b.value), int(q.value)
+
     def profile_enable(self, on: bool) -> None:
         _raise(self._L.vl_index_profile_enable(self._h, 1 if on else 0))
 

@@ -7,6 +7,8 @@
 // src/index/flat.rs:106-114).  There is no CPU compute fallback.
 #include "flat_index.hpp"
 
+#include <chrono>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -423,6 +425,137 @@ void GpuFlatIndex::profile_read(uint64_t* n, double* ms, uint64_t* bytes)
 // ---------------------------------------------------------------------------------------------
 int GpuFlatIndex::search(const double* query, uint64_t q_len, uint64_t k, int metric, uint64_t* out_pos,
                          uint64_t* out_ids, double* out_scores, uint64_t* out_n) const
+{
+    if (co_max_.load(std::memory_order_relaxed) > 1)
+        return search_coalesced(query, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
+    return search_direct(query, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Coalescing of concurrent single-query calls (SURVEY 8(b) threading row / 8(f) f1).
+// The reference serves many searches at once under RwLock::read (src/client.rs:398, one tokio
+// worker each); every one of them walks the whole slab.  Here concurrent callers share slab passes:
+// a caller that finds no batch in flight becomes the leader, takes every queued request with its own
+// (metric, k) -- all that piled up while the previous batch was on the GPU -- and answers them with
+// ONE search_batch() pass; the others sleep until their request is marked done.  Every caller still
+// receives exactly what search_direct() would have returned (search_batch's contract); a batch that
+// fails as a whole (e.g. a NaN score for one member) is redone one by one so errors stay per caller.
+// ---------------------------------------------------------------------------------------------
+struct GpuFlatIndex::CoalesceReq {
+    const double* query;
+    uint64_t k;
+    int metric;
+    uint64_t* out_pos;
+    uint64_t* out_ids;
+    double* out_scores;
+    uint64_t* out_n;
+    int rc = OK;
+    int path = PATH_NONE;
+    std::string err;
+    bool done = false;
+};
+
+int GpuFlatIndex::search_coalesced(const double* query, uint64_t q_len, uint64_t k, int metric, uint64_t* out_pos,
+                                   uint64_t* out_ids, double* out_scores, uint64_t* out_n) const
+{
+    if (!out_n) return ERR_INVALID_ARG;
+    *out_n = 0;
+    {   // everything that can fail or finish without touching the slab is settled on the calling thread
+        std::shared_lock<std::shared_mutex> lk(mu_);
+        const uint64_t n = ids_.size();
+        if (metric < 0 || metric > 3 || (n != 0 && q_len != dim_) || n == 0 || k == 0 || (!query && dim_) || !out_scores ||
+            force_path_.load() != 0)
+            goto direct;
+    }
+    {
+        CoalesceReq r{query, k, metric, out_pos, out_ids, out_scores, out_n};
+        const size_t max_batch = (size_t)std::max(2, co_max_.load());
+        std::unique_lock<std::mutex> lk(co_mu_);
+        co_q_.push_back(&r);
+        co_cv_.notify_all();  // a leader waiting in its window counts arrivals
+        while (!r.done) {
+            if (co_leader_) {
+                co_cv_.wait(lk);
+                continue;
+            }
+            co_leader_ = true;
+            const int window = co_window_us_.load();
+            if (window > 0 && co_q_.size() < max_batch)
+                co_cv_.wait_for(lk, std::chrono::microseconds(window), [&] { return co_q_.size() >= max_batch; });
+            std::vector<CoalesceReq*> batch;
+            batch.push_back(&r);
+            for (auto it = co_q_.begin(); it != co_q_.end();) {
+                CoalesceReq* o = *it;
+                if (o == &r) {
+                    it = co_q_.erase(it);
+                } else if (o->metric == r.metric && o->k == r.k && batch.size() < max_batch) {
+                    batch.push_back(o);
+                    it = co_q_.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+            lk.unlock();
+            run_coalesced(batch);
+            lk.lock();
+            for (CoalesceReq* o : batch) o->done = true;
+            co_leader_ = false;
+            co_cv_.notify_all();
+        }
+        lk.unlock();
+        set_last_path(r.path);
+        if (r.rc != OK) set_last_error(r.err);
+        return r.rc;
+    }
+direct:
+    return search_direct(query, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
+}
+
+void GpuFlatIndex::run_coalesced(std::vector<CoalesceReq*>& batch) const
+{
+    co_batches_.fetch_add(1);
+    co_queries_.fetch_add(batch.size());
+    auto one = [&](CoalesceReq* o) {
+        o->rc = search_direct(o->query, dim_, o->k, o->metric, o->out_pos, o->out_ids, o->out_scores, o->out_n);
+        o->path = last_path();
+        if (o->rc != OK) o->err = last_error();
+    };
+    if (batch.size() == 1) {
+        one(batch[0]);
+        return;
+    }
+    const uint64_t nq = batch.size(), k = batch[0]->k;
+    int rc = OK;
+    try {
+        std::vector<double> q(nq * dim_);
+        for (uint64_t i = 0; i < nq; ++i) std::memcpy(q.data() + i * dim_, batch[i]->query, dim_ * sizeof(double));
+        std::vector<uint64_t> pos(nq * k), ids(nq * k), cnt(nq);
+        std::vector<double> scores(nq * k);
+        rc = search_batch(q.data(), nq, dim_, k, batch[0]->metric, pos.data(), ids.data(), scores.data(), cnt.data());
+        if (rc == OK) {
+            const int path = last_path();
+            for (uint64_t i = 0; i < nq; ++i) {
+                CoalesceReq* o = batch[i];
+                const uint64_t m = cnt[i];
+                for (uint64_t j = 0; j < m; ++j) {
+                    if (o->out_pos) o->out_pos[j] = pos[i * k + j];
+                    if (o->out_ids) o->out_ids[j] = ids[i * k + j];
+                    o->out_scores[j] = scores[i * k + j];
+                }
+                *o->out_n = m;
+                o->rc = OK;
+                o->path = path;
+            }
+            return;
+        }
+    } catch (const std::bad_alloc&) {
+        rc = ERR_OOM;
+    }
+    for (CoalesceReq* o : batch) one(o);  // per-caller errors (src/index/flat.rs:116 panics only the offending search)
+}
+
+int GpuFlatIndex::search_direct(const double* query, uint64_t q_len, uint64_t k, int metric, uint64_t* out_pos,
+                                uint64_t* out_ids, double* out_scores, uint64_t* out_n) const
 {
     if (!out_n) return ERR_INVALID_ARG;
     *out_n = 0;

@@ -9,6 +9,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
@@ -122,6 +123,18 @@ public:
         bf16_tries_.store(0);
         bf16_fails_.store(0);
     }
+    // Group concurrent single-query search() calls into shared slab passes (see search_coalesced()).
+    // max_batch <= 1 turns it off (default).  window_us: how long a lone caller waits for company.
+    void set_coalescing(int max_batch, int window_us)
+    {
+        co_window_us_.store(window_us < 0 ? 0 : window_us);
+        co_max_.store(max_batch < 0 ? 0 : (max_batch > (int)MFMA_MAX_BATCH ? (int)MFMA_MAX_BATCH : max_batch));
+    }
+    void coalesce_stats(uint64_t* batches, uint64_t* queries) const
+    {
+        if (batches) *batches = co_batches_.load();
+        if (queries) *queries = co_queries_.load();
+    }
     void profile_enable(bool on);
     void profile_read(uint64_t* n, double* ms, uint64_t* bytes);
     int device() const { return device_; }
@@ -135,6 +148,12 @@ private:
     Workspace* acquire_ws() const;
     void release_ws(Workspace* ws) const;
     int prepare_ws(Workspace* ws) const;
+    struct CoalesceReq;
+    int search_direct(const double* query, uint64_t q_len, uint64_t k, int metric, uint64_t* out_pos, uint64_t* out_ids,
+                      double* out_scores, uint64_t* out_n) const;
+    int search_coalesced(const double* query, uint64_t q_len, uint64_t k, int metric, uint64_t* out_pos,
+                         uint64_t* out_ids, double* out_scores, uint64_t* out_n) const;
+    void run_coalesced(std::vector<CoalesceReq*>& batch) const;
     int search_locked(Workspace* ws, const double* query, uint64_t k_eff, int metric, uint64_t* out_pos,
                       uint64_t* out_ids, double* out_scores, uint64_t* out_n, bool skip_fast) const;
     int run_exact(Workspace* ws, int metric, uint64_t n, uint64_t k_eff, std::vector<uint32_t>* pos,
@@ -178,6 +197,14 @@ private:
     mutable std::mutex ws_mu_;
     mutable std::vector<Workspace*> ws_free_;
     mutable std::vector<std::unique_ptr<Workspace>> ws_all_;
+
+    // coalescing queue (leader/follower: the caller that finds no batch in flight runs the next one)
+    mutable std::mutex co_mu_;
+    mutable std::condition_variable co_cv_;
+    mutable std::deque<CoalesceReq*> co_q_;
+    mutable bool co_leader_ = false;
+    std::atomic<int> co_max_{0}, co_window_us_{0};
+    mutable std::atomic<uint64_t> co_batches_{0}, co_queries_{0};
 
     std::atomic<int> force_path_{0};
     std::atomic<int> single_filter_{0};
