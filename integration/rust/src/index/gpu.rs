@@ -1,0 +1,297 @@
+//! GPU-resident indexes for vectorlite: `impl VectorIndex` over libvectorlite_amd.so
+//! (C ABI: include/vectorlite_amd.h of the vectorlite_amd repository).
+//!
+//! NOT compiled in the repository that ships it (its image has no Rust toolchain); every `extern`
+//! signature below is checked against the header by tests/test_rust_binding_signatures.py.
+//!
+//! Vectors live in HBM (f64 master rows + an f32 scan slab); `text` / `metadata` stay on the host in a
+//! side table keyed by id and are re-attached to the k winners only (the CPU FlatIndex clones them for
+//! all N rows before sorting).
+use std::collections::HashMap;
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_int};
+
+use serde::{Deserialize, Deserializer, Serialize, Serializer};
+
+use crate::errors::{VectorLiteError, VectorLiteResult};
+use crate::{SearchResult, SimilarityMetric, Vector, VectorIndex};
+
+#[repr(C)]
+pub struct vl_index {
+    _private: [u8; 0],
+}
+
+extern "C" {
+    fn vl_flat_create(dim: u64, device: c_int, out: *mut *mut vl_index) -> c_int;
+    fn vl_flat_from_rows(dim: u64, ids: *const u64, values: *const f64, n: u64, device: c_int, out: *mut *mut vl_index) -> c_int;
+    fn vl_hnsw_create(dim: u64, metric: c_int, device: c_int, out: *mut *mut vl_index) -> c_int;
+    fn vl_index_clone(h: *const vl_index, out: *mut *mut vl_index) -> c_int;
+    fn vl_index_destroy(h: *mut vl_index);
+    fn vl_index_add(h: *mut vl_index, id: u64, values: *const f64, len: u64) -> c_int;
+    fn vl_index_add_bulk(h: *mut vl_index, ids: *const u64, values: *const f64, n: u64, validate: c_int, values_on_device: c_int) -> c_int;
+    fn vl_index_delete(h: *mut vl_index, id: u64) -> c_int;
+    fn vl_index_search(h: *const vl_index, query: *const f64, q_len: u64, k: u64, metric: c_int, out_ids: *mut u64, out_scores: *mut f64, out_n: *mut u64) -> c_int;
+    fn vl_index_len(h: *const vl_index) -> u64;
+    fn vl_index_get_vector(h: *const vl_index, id: u64, out: *mut f64) -> c_int;
+    fn vl_index_export(h: *const vl_index, out_ids: *mut u64, out_values: *mut f64) -> c_int;
+    fn vl_index_set_coalescing(h: *mut vl_index, max_batch: c_int, window_us: c_int) -> c_int;
+    fn vl_last_error() -> *const c_char;
+    fn vl_last_dim_mismatch(expected: *mut u64, actual: *mut u64);
+}
+
+const VL_OK: c_int = 0;
+const VL_ERR_DIM_MISMATCH: c_int = 1;
+const VL_ERR_DUP_ID: c_int = 2;
+const VL_ERR_NOT_FOUND: c_int = 3;
+const VL_ERR_METRIC_MISMATCH: c_int = 4;
+const VL_ERR_NAN_SCORE: c_int = 5;
+
+fn last_error() -> String {
+    unsafe { CStr::from_ptr(vl_last_error()).to_string_lossy().into_owned() }
+}
+
+/// Declaration order of `enum SimilarityMetric` = the ABI's metric codes.
+fn metric_code(m: SimilarityMetric) -> c_int {
+    match m {
+        SimilarityMetric::Cosine => 0,
+        SimilarityMetric::Euclidean => 1,
+        SimilarityMetric::Manhattan => 2,
+        SimilarityMetric::DotProduct => 3,
+    }
+}
+
+type Side = HashMap<u64, (String, Option<serde_json::Value>)>;
+
+/// Shared body of the two index types: the handle dispatches like `VectorIndexWrapper`.
+#[derive(Debug)]
+struct Handle {
+    raw: *mut vl_index,
+    dim: usize,
+    side: Side,
+}
+// The library takes its own locks: searches are re-entrant (callers hold RwLock::read together),
+// add/delete take the handle exclusively.
+unsafe impl Send for Handle {}
+unsafe impl Sync for Handle {}
+
+impl Drop for Handle {
+    fn drop(&mut self) {
+        unsafe { vl_index_destroy(self.raw) }
+    }
+}
+
+impl Clone for Handle {
+    fn clone(&self) -> Self {
+        let mut raw = std::ptr::null_mut();
+        let rc = unsafe { vl_index_clone(self.raw, &mut raw) };
+        assert_eq!(rc, VL_OK, "vl_index_clone: {}", last_error());
+        Handle { raw, dim: self.dim, side: self.side.clone() }
+    }
+}
+
+impl Handle {
+    fn add(&mut self, v: Vector) -> Result<(), String> {
+        match unsafe { vl_index_add(self.raw, v.id, v.values.as_ptr(), v.values.len() as u64) } {
+            VL_OK => {
+                self.side.insert(v.id, (v.text, v.metadata));
+                Ok(())
+            }
+            VL_ERR_DIM_MISMATCH => Err("Vector dimension mismatch".to_string()),
+            VL_ERR_DUP_ID => Err(format!("Vector ID {} already exists", v.id)),
+            _ => Err(last_error()),
+        }
+    }
+
+    fn search(&self, query: &[f64], k: usize, metric: SimilarityMetric) -> VectorLiteResult<Vec<SearchResult>> {
+        let cap = k.min(self.len()).max(1);
+        let (mut ids, mut scores, mut n) = (vec![0u64; cap], vec![0f64; cap], 0u64);
+        let rc = unsafe {
+            vl_index_search(self.raw, query.as_ptr(), query.len() as u64, k as u64, metric_code(metric), ids.as_mut_ptr(), scores.as_mut_ptr(), &mut n)
+        };
+        match rc {
+            VL_OK => Ok((0..n as usize)
+                .map(|i| {
+                    let (text, metadata) = self.side.get(&ids[i]).cloned().unwrap_or_default();
+                    SearchResult { id: ids[i], score: scores[i], text, metadata }
+                })
+                .collect()),
+            VL_ERR_DIM_MISMATCH => {
+                let (mut e, mut a) = (0u64, 0u64);
+                unsafe { vl_last_dim_mismatch(&mut e, &mut a) };
+                Err(VectorLiteError::DimensionMismatch { expected: e as usize, actual: a as usize })
+            }
+            VL_ERR_METRIC_MISMATCH => Err(VectorLiteError::InternalError(last_error())), // caller maps to MetricMismatch
+            VL_ERR_NAN_SCORE => panic!("NaN similarity score"), // what partial_cmp().unwrap() does on the CPU index
+            _ => Err(VectorLiteError::InternalError(last_error())),
+        }
+    }
+
+    fn len(&self) -> usize {
+        unsafe { vl_index_len(self.raw) as usize }
+    }
+
+    fn get_vector(&self, id: u64) -> Option<Vector> {
+        let mut values = vec![0f64; self.dim];
+        if unsafe { vl_index_get_vector(self.raw, id, values.as_mut_ptr()) } != VL_OK {
+            return None;
+        }
+        let (text, metadata) = self.side.get(&id).cloned().unwrap_or_default();
+        Some(Vector { id, values, text, metadata })
+    }
+
+    /// (ids, row-major values) of every live row, insertion order: the serde payload.
+    fn export(&self) -> (Vec<u64>, Vec<f64>) {
+        let n = self.len();
+        let (mut ids, mut values) = (vec![0u64; n], vec![0f64; n * self.dim]);
+        if n > 0 {
+            let rc = unsafe { vl_index_export(self.raw, ids.as_mut_ptr(), values.as_mut_ptr()) };
+            assert_eq!(rc, VL_OK, "vl_index_export: {}", last_error());
+        }
+        (ids, values)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Flat
+// ------------------------------------------------------------------------------------------------
+#[derive(Debug, Clone)]
+pub struct GpuFlatIndex(Handle);
+
+impl GpuFlatIndex {
+    /// Mirrors `FlatIndex::new(dim, data)`: no validation of `data`.
+    pub fn new(dim: usize, data: Vec<Vector>) -> Self {
+        let ids: Vec<u64> = data.iter().map(|v| v.id).collect();
+        let mut values = Vec::with_capacity(data.len() * dim);
+        for v in &data {
+            values.extend_from_slice(&v.values);
+        }
+        let mut raw = std::ptr::null_mut();
+        let rc = unsafe { vl_flat_from_rows(dim as u64, ids.as_ptr(), values.as_ptr(), ids.len() as u64, 0, &mut raw) };
+        assert_eq!(rc, VL_OK, "vl_flat_from_rows: {}", last_error());
+        let mut side = Side::new();
+        for v in data {
+            side.entry(v.id).or_insert((v.text, v.metadata)); // first row of an id wins, like get_vector's find()
+        }
+        // tokio workers search concurrently under RwLock::read: let them share slab passes
+        unsafe { vl_index_set_coalescing(raw, 64, 200) };
+        GpuFlatIndex(Handle { raw, dim, side })
+    }
+}
+
+impl VectorIndex for GpuFlatIndex {
+    fn add(&mut self, vector: Vector) -> Result<(), String> {
+        self.0.add(vector)
+    }
+    fn delete(&mut self, id: u64) -> Result<(), String> {
+        unsafe { vl_index_delete(self.0.raw, id) }; // a missing id is Ok for the flat index
+        self.0.side.remove(&id);
+        Ok(())
+    }
+    fn search(&self, query: &[f64], k: usize, metric: SimilarityMetric) -> VectorLiteResult<Vec<SearchResult>> {
+        self.0.search(query, k, metric)
+    }
+    fn len(&self) -> usize {
+        self.0.len()
+    }
+    fn is_empty(&self) -> bool {
+        self.0.len() == 0
+    }
+    fn get_vector(&self, id: u64) -> Option<Vector> {
+        self.0.get_vector(id)
+    }
+    fn dimension(&self) -> usize {
+        self.0.dim
+    }
+}
+
+/// Same on-disk payload as the CPU `FlatIndex` (`{dim, data: [Vector]}`): .vlc files stay interchangeable.
+#[derive(Serialize, Deserialize)]
+struct FlatPayload {
+    dim: usize,
+    data: Vec<Vector>,
+}
+
+impl Serialize for GpuFlatIndex {
+    fn serialize<S: Serializer>(&self, s: S) -> Result<S::Ok, S::Error> {
+        let (ids, values) = self.0.export();
+        let dim = self.0.dim;
+        let data = ids
+            .iter()
+            .enumerate()
+            .map(|(i, &id)| {
+                let (text, metadata) = self.0.side.get(&id).cloned().unwrap_or_default();
+                Vector { id, values: values[i * dim..(i + 1) * dim].to_vec(), text, metadata }
+            })
+            .collect();
+        FlatPayload { dim, data }.serialize(s)
+    }
+}
+
+impl<'de> Deserialize<'de> for GpuFlatIndex {
+    fn deserialize<D: Deserializer<'de>>(d: D) -> Result<Self, D::Error> {
+        let p = FlatPayload::deserialize(d)?;
+        Ok(GpuFlatIndex::new(p.dim, p.data))
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// HNSW (graph built and walked on the GPU; tombstone deletes, ef = min(k, len), metric fixed at creation)
+// ------------------------------------------------------------------------------------------------
+#[derive(Debug, Clone)]
+pub struct GpuHnswIndex {
+    h: Handle,
+    metric: SimilarityMetric,
+}
+
+impl GpuHnswIndex {
+    pub fn new(dim: usize, metric: SimilarityMetric) -> Self {
+        let mut raw = std::ptr::null_mut();
+        let rc = unsafe { vl_hnsw_create(dim as u64, metric_code(metric), 0, &mut raw) };
+        assert_eq!(rc, VL_OK, "vl_hnsw_create: {}", last_error());
+        GpuHnswIndex { h: Handle { raw, dim, side: Side::new() }, metric }
+    }
+    pub fn metric(&self) -> SimilarityMetric {
+        self.metric
+    }
+    /// Bulk insert (one batched graph build on the device) for the custom Deserialize.
+    pub fn add_all(&mut self, ids: &[u64], values: &[f64]) -> Result<(), String> {
+        match unsafe { vl_index_add_bulk(self.h.raw, ids.as_ptr(), values.as_ptr(), ids.len() as u64, 1, 0) } {
+            VL_OK => Ok(()),
+            _ => Err(last_error()),
+        }
+    }
+}
+
+impl VectorIndex for GpuHnswIndex {
+    fn add(&mut self, vector: Vector) -> Result<(), String> {
+        self.h.add(vector)
+    }
+    fn delete(&mut self, id: u64) -> Result<(), String> {
+        match unsafe { vl_index_delete(self.h.raw, id) } {
+            VL_OK => {
+                self.h.side.remove(&id);
+                Ok(())
+            }
+            VL_ERR_NOT_FOUND => Err(format!("Vector ID {} does not exist", id)),
+            _ => Err(last_error()),
+        }
+    }
+    fn search(&self, query: &[f64], k: usize, metric: SimilarityMetric) -> VectorLiteResult<Vec<SearchResult>> {
+        if metric != self.metric {
+            return Err(VectorLiteError::MetricMismatch { requested: metric, index: self.metric });
+        }
+        self.h.search(query, k, metric)
+    }
+    fn len(&self) -> usize {
+        self.h.len()
+    }
+    fn is_empty(&self) -> bool {
+        self.h.len() == 0
+    }
+    fn get_vector(&self, id: u64) -> Option<Vector> {
+        self.h.get_vector(id)
+    }
+    fn dimension(&self) -> usize {
+        self.h.dim
+    }
+}
