@@ -48,7 +48,13 @@ typedef enum vl_status {
     VL_ERR_NAN_SCORE = 5,       /* stands in for the partial_cmp().unwrap() panic, src/index/flat.rs:116 */
     VL_ERR_DEVICE = 6,          /* HIP runtime / kernel failure, or no device */
     VL_ERR_OOM = 7,             /* host or device allocation failed */
-    VL_ERR_INVALID_ARG = 8      /* null pointer, unknown metric, ... */
+    VL_ERR_INVALID_ARG = 8,     /* null pointer, unknown metric, ... */
+    /* .vlc loader (PersistenceError, src/persistence.rs:34-54) */
+    VL_ERR_IO = 9,               /* "IO error: {0}" */
+    VL_ERR_FILE_NOT_FOUND = 10,  /* "File not found: {0}" */
+    VL_ERR_SERIALIZATION = 11,   /* "Serialization error: {0}" (malformed JSON, missing field, bad row) */
+    VL_ERR_VERSION_MISMATCH = 12,/* "Version mismatch: expected 1.0.0, got {actual}" */
+    VL_ERR_INVALID_FORMAT = 13   /* "Invalid file format: Expected format 'vectorlite-collection', got '{}'" */
 } vl_status;
 
 /* Which search pipeline produced the last result on this thread (diagnostics). */
@@ -144,6 +150,31 @@ int vl_index_max_id(const vl_index *h, uint64_t *out_id);
 
 /* Rows in storage order, for Serialize (src/index/flat.rs:59): ids[len], values[len, dim]. */
 int vl_index_export(const vl_index *h, uint64_t *out_ids, double *out_values);
+
+/* ---- .vlc collection files (src/persistence.rs:149-176; the step before the path) --------- */
+
+/* load_collection_from_file without materialising CollectionData: the file is mapped, one structural
+ * pass locates every row's `values` / `text` / `metadata` tokens, header.version and header.format
+ * are validated after the document has been accepted (the reference's order), and the numbers are
+ * converted by host threads straight into staging blocks that are ingested on the device.
+ * vl_vlc_open does host work only (usable without a GPU); vl_vlc_build_index creates the GPU index
+ * ("Flat" payload: FlatIndex{dim, data} taken as is, duplicate ids kept, src/index/flat.rs:59;
+ * "HNSW" payload: every vector re-inserted, src/index/hnsw.rs:272-360, in file order). */
+typedef struct vl_vlc_doc vl_vlc_doc;
+int vl_vlc_open(const char *path, vl_vlc_doc **out);
+void vl_vlc_close(vl_vlc_doc *doc);
+const char *vl_vlc_name(const vl_vlc_doc *doc); /* metadata.name, UTF-8; valid until vl_vlc_close */
+/* index_type 0 = Flat / 1 = HNSW; metric -1 for Flat; dim = the payload's dim; rows = vectors found;
+ * vector_count / dimension = the metadata block's fields (informational, like the reference). */
+int vl_vlc_info(const vl_vlc_doc *doc, int *index_type, int *metric, uint64_t *dim, uint64_t *rows,
+                uint64_t *vector_count, uint64_t *dimension);
+/* Per row, file order: id and the byte ranges (offset, length) in the file of its `text` string token
+ * (quotes included) and `metadata` value token; length 0 = absent.  Arrays of `rows` entries. */
+int vl_vlc_side_table(const vl_vlc_doc *doc, uint64_t *ids, uint64_t *text_off, uint64_t *text_len,
+                      uint64_t *meta_off, uint64_t *meta_len);
+/* rows [first, first + n) converted to out[n, dim] f64 on the host (correctly rounded). */
+int vl_vlc_read_values(const vl_vlc_doc *doc, uint64_t first, uint64_t n, double *out_values);
+int vl_vlc_build_index(const vl_vlc_doc *doc, int device, vl_index **out);
 
 /* ---- multi-GPU row shards (no reference counterpart) ---------------------- */
 

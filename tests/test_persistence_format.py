@@ -67,3 +67,167 @@ def test_hnsw_vlc_round_trip(tmp_path):
     assert isinstance(back, V.HNSWIndex) and len(back) == 4 and back.metric() == V.SimilarityMetric.Euclidean
     res = back.search([1.1, 0.1, 0.1], 2, V.SimilarityMetric.Euclidean)  # src/index/hnsw.rs:736-742
     assert res[0].id == 1 and res[0].text == "t1"
+
+
+# ---- native streaming reader (csrc/vlc_loader.cpp): host-only part, no GPU needed --------------------
+def _write(tmp_path, doc, name="c.vlc", **kw):
+    p = tmp_path / name
+    p.write_text(doc if isinstance(doc, str) else json.dumps(doc, **kw))
+    return str(p)
+
+
+def test_native_reader_structure_and_values(tmp_path):
+    from vectorlite_amd import persistence as P
+    rng = np.random.default_rng(3)
+    n, dim = 700, 9
+    rows = rng.standard_normal((n, dim)) * np.exp(rng.uniform(-40, 40, size=(n, 1)))
+    rows[5] = [0.0, -0.0, 1.0, -1.0, 1e-320, 5e-324, 1.7976931348623157e308, 123456789012345678.0, 3.0]
+    data = [{"id": int(i * 7 + 1), "values": rows[i].tolist(), "text": f"t{i} \"q\" \\ é中\U0001F600\n",
+             "metadata": None if i % 3 == 0 else {"k": [i, "]", {"x": "}\""}], "s": "a\"]b"}} for i in range(n)]
+    doc = _doc()
+    doc["metadata"].update(name="näme \"x\"", vector_count=n, dimension=dim)
+    doc["index"] = {"Flat": {"dim": dim, "data": data}}
+    for kw in ({"indent": 2}, {"separators": (",", ":")}, {"ensure_ascii": False, "indent": 1}):
+        d = P.VlcDocument(_write(tmp_path, doc, **kw))
+        assert (d.index_type, d.metric, d.dim, d.rows, d.vector_count, d.dimension) == ("Flat", None, dim, n, n, dim)
+        assert d.name == "näme \"x\""
+        got = d.values()
+        assert got.shape == (n, dim) and np.array_equal(got.view(np.uint64), rows.view(np.uint64))  # bit for bit, -0.0 too
+        assert np.array_equal(d.values(10, 5).view(np.uint64), rows[10:15].view(np.uint64))
+        side = d.side_data(first_wins=True)
+        assert list(side.keys()) == [r["id"] for r in data]
+        assert all(side[r["id"]] == (r["text"], r["metadata"]) for r in data)
+        d.close()
+
+
+def test_native_reader_field_order_unknown_fields_and_integers(tmp_path):
+    from vectorlite_amd import persistence as P
+    text = '''{"index": {"Flat": {"extra": [1, {"a": "]"}], "data": [
+        {"metadata": {"a": 1}, "text": "x", "values": [1, -2, 3e0, 4.5E+1], "id": 18446744073709551615, "zzz": null},
+        {"id": 0, "values": [ 0.1 ,0.2,
+            0.3, 1e-7 ], "text": ""}], "dim": 4}},
+      "metadata": {"index_type": "Flat", "dimension": 4, "vector_count": 2, "created_at": "x", "name": "n"},
+      "header": {"created_at": "2025-01-01T00:00:00Z", "format": "vectorlite-collection", "version": "1.0.0"}}'''
+    d = P.VlcDocument(_write(tmp_path, text))
+    assert d.rows == 2 and d.dim == 4
+    assert d.values().tolist() == [[1.0, -2.0, 3.0, 45.0], [0.1, 0.2, 0.3, 1e-7]]
+    ids = d.side_table()[0].tolist()
+    assert ids == [18446744073709551615, 0]
+    assert d.side_data(True) == {18446744073709551615: ("x", {"a": 1}), 0: ("", None)}
+
+
+def test_native_reader_hnsw_payload(tmp_path):
+    from vectorlite_amd import persistence as P
+    import vectorlite_amd as V
+    doc = _doc()
+    doc["metadata"]["index_type"] = "HNSW"
+    doc["index"] = {"HNSW": {"dim": 3, "metric": "Euclidean", "id_to_index": {"5": 0, "9": 1}, "index_to_id": {"0": 5, "1": 9},
+                             "metadata": {"9": {"text": "nine", "metadata": {"a": 1}}, "5": {"text": "five", "metadata": None}},
+                             "vector_values": {"5": [1.0, 0.0, 0.0], "9": [0.0, 1.0, 0.5]}}}
+    d = P.VlcDocument(_write(tmp_path, doc, indent=2))
+    assert (d.index_type, d.metric, d.dim, d.rows) == ("HNSW", V.SimilarityMetric.Euclidean, 3, 2)
+    assert d.values().tolist() == [[1.0, 0.0, 0.0], [0.0, 1.0, 0.5]]
+    assert d.side_data(False) == {5: ("five", None), 9: ("nine", {"a": 1})}
+    doc["index"]["HNSW"]["dim"] = 0
+    with pytest.raises(P.PersistenceError, match="Invalid dimension: cannot be 0"):  # src/index/hnsw.rs:288-290
+        P.VlcDocument(_write(tmp_path, doc))
+    doc["index"]["HNSW"].update(dim=3, metric="Chebyshev")
+    with pytest.raises(P.PersistenceError, match="unknown variant `Chebyshev`"):
+        P.VlcDocument(_write(tmp_path, doc))
+
+
+def test_native_reader_errors_match_reference_categories(tmp_path):
+    """src/persistence.rs:149-176 (+ its tests :293-351): serde errors first, then version, then format."""
+    from vectorlite_amd import persistence as P
+    with pytest.raises(P.FileNotFound):
+        P.VlcDocument(str(tmp_path / "missing.vlc"))
+    with pytest.raises(P.VersionMismatch) as e:
+        P.VlcDocument(_write(tmp_path, _doc(version="2.0.0")))
+    assert (e.value.expected, e.value.actual) == ("1.0.0", "2.0.0")
+    with pytest.raises(P.InvalidFormat, match="Expected format 'vectorlite-collection', got 'invalid-format'"):
+        P.VlcDocument(_write(tmp_path, _doc(fmt="invalid-format")))
+    both = _doc(version="9", fmt="nope")  # version is checked before format (:160-173)
+    with pytest.raises(P.VersionMismatch):
+        P.VlcDocument(_write(tmp_path, both))
+    bad_and_wrong_version = json.dumps(_doc(version="2.0.0"))[:-3]  # malformed document: serde speaks first
+    for text in ("", "{not json", "[]", bad_and_wrong_version, json.dumps(_doc()) + " x",
+                 json.dumps({k: v for k, v in _doc().items() if k != "header"})):
+        with pytest.raises(P.PersistenceError, match="Serialization error"):
+            P.VlcDocument(_write(tmp_path, text))
+
+    def flat(rows, dim=3):
+        d = _doc()
+        d["index"] = {"Flat": {"dim": dim, "data": rows}}
+        return d
+    for rows, msg in (([{"id": 1, "values": [1, 2, 3]}], "missing field `text`"),
+                      ([{"id": -1, "values": [1, 2, 3], "text": ""}], "expected u64"),
+                      ([{"id": 1.5, "values": [1, 2, 3], "text": ""}], "floating point"),
+                      ([{"values": [1, 2, 3], "text": ""}], "missing field `id`"),
+                      ([{"id": 1, "values": 7, "text": ""}], "expected a sequence"),
+                      ([{"id": 1, "values": [1, 2, 3], "text": 5}], "expected a string")):
+        with pytest.raises(P.PersistenceError, match=msg):
+            P.VlcDocument(_write(tmp_path, flat(rows)))
+    # rows are converted lazily: bad numbers / ragged rows surface when the values are read
+    for vals, msg in (("[1, 2]", "Vector dimension mismatch: expected 3, got 2"), ("[1, 2, 3, 4]", "expected 3, got 4"),
+                      ("[1, 2, x]", "expected f64"), ("[1, 2, 01]", "invalid number"), ("[1, 2, 1e999]", "out of range"),
+                      ("[1, 2, 3,]", "expected f64"), ("[1, 2, +3]", "expected f64"), ("[1, 2, NaN]", "expected f64"),
+                      ("[1, 2, 1.]", "invalid number"), ("[1 2 3]", "expected `,` or `]`")):
+        text = json.dumps(flat([{"id": 1, "values": "@@", "text": ""}])).replace('"@@"', vals)
+        d = P.VlcDocument(_write(tmp_path, text))
+        with pytest.raises(P.PersistenceError, match=msg):
+            d.values()
+
+
+def test_native_reader_large_file_parallel_conversion(tmp_path):
+    """40k x 64 rows (~50 MB of JSON): the threaded conversion returns exactly what Python's json does."""
+    from vectorlite_amd import persistence as P
+    rng = np.random.default_rng(9)
+    n, dim = 40000, 64
+    rows = rng.standard_normal((n, dim))
+    p = tmp_path / "big.vlc"
+    with open(p, "w") as f:
+        f.write('{"header": {"version": "1.0.0", "format": "vectorlite-collection", "created_at": "x"},\n'
+                '"metadata": {"name": "big", "created_at": "x", "vector_count": %d, "dimension": %d, "index_type": "Flat"},\n'
+                '"index": {"Flat": {"dim": %d, "data": [\n' % (n, dim, dim))
+        for i in range(n):
+            f.write('{"id": %d, "values": %s, "text": "row %d", "metadata": null}%s\n'
+                    % (i, json.dumps(rows[i].tolist()), i, "," if i + 1 < n else ""))
+        f.write("]}}}\n")
+    d = P.VlcDocument(str(p))
+    assert d.rows == n
+    assert np.array_equal(d.values(), rows)
+    assert d.side_data(True)[n - 1] == (f"row {n - 1}", None)
+
+
+@pytest.mark.gpu
+def test_native_loader_builds_the_same_index_as_bulk_add(tmp_path):
+    """vl_vlc_build_index (chunked, conversion overlapped with ingest) == add_rows of the same rows:
+    duplicate ids kept (FlatIndex{dim, data} is not validated, src/index/flat.rs:59), search identical."""
+    import vectorlite_amd as V
+    from vectorlite_amd import persistence as P
+    rng = np.random.default_rng(4)
+    n, dim = 3000, 48
+    rows = rng.standard_normal((n, dim))
+    ids = np.arange(n, dtype=np.uint64) * 3
+    ids[10] = ids[2]  # duplicate id, kept
+    doc = _doc()
+    doc["index"] = {"Flat": {"dim": dim, "data": [
+        {"id": int(ids[i]), "values": rows[i].tolist(), "text": f"t{i}", "metadata": {"i": i}} for i in range(n)]}}
+    p = tmp_path / "n.vlc"
+    p.write_text(json.dumps(doc))
+    name, idx = P.load_collection_from_file(str(p))
+    ref = V.FlatIndex(dim)
+    ref.add_rows(ids, rows, validate=False)
+    gi, gv = idx.export()
+    assert gi.tolist() == ids.tolist() and np.array_equal(gv, rows)
+    for m in range(4):
+        a, b = idx.search_arrays(rows[7] + 0.01, 20, m), ref.search_arrays(rows[7] + 0.01, 20, m)
+        assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist()
+    assert idx.get_vector(int(ids[2])).text == "t2"  # first row of a duplicated id
+    res = idx.search(rows[5], 1, V.SimilarityMetric.Cosine)
+    assert res[0].id == int(ids[5]) and res[0].metadata == {"i": 5}
+    ragged = _doc()
+    ragged["index"]["Flat"]["data"][1]["values"] = [1.0, 2.0]
+    p.write_text(json.dumps(ragged))
+    with pytest.raises(P.PersistenceError, match="Vector dimension mismatch: expected 3, got 2"):
+        P.load_collection_from_file(str(p))

@@ -376,11 +376,14 @@ class HNSWIndex:
     (crate hnsw 0.11.0 is not in the reference tree), so results are approximate: judged by recall."""
 
     def __init__(self, dim: int, metric: int = SimilarityMetric.Cosine, device: int = 0, m: int = 16, m0: int = 32,
-                 ef_construction: int = 128, seed: int = 0):
+                 ef_construction: int = 128, seed: int = 0, _handle=None):
         self._L = _lib.load()
         self._meta: Dict[int, Tuple[str, Any]] = {}
         self._h = C.c_void_p()
         self.device = device
+        if _handle is not None:  # adopt a handle made by the library (vl_vlc_build_index)
+            self._h = _handle
+            return
         if dim == 0:
             raise ValueError("HNSW index dimension cannot be 0")  # panics in the reference (:217-219)
         _raise(self._L.vl_hnsw_create_ex(dim, int(metric), m, m0, ef_construction, seed, device, C.byref(self._h)))

@@ -20,6 +20,7 @@ SYMBOLS = [
     "vl_index_export", "vl_index_search_positions", "vl_index_search_batch_positions", "vl_index_hnsw_distances", "vl_hnsw_score",
     "vl_last_error", "vl_last_dim_mismatch", "vl_last_path", "vl_index_force_path", "vl_index_set_single_filter",
     "vl_index_set_coalescing", "vl_index_coalesce_stats",
+    "vl_vlc_open", "vl_vlc_close", "vl_vlc_name", "vl_vlc_info", "vl_vlc_side_table", "vl_vlc_read_values", "vl_vlc_build_index",
     "vl_index_profile_enable", "vl_index_profile_read", "vl_runtime_info",
 ]
 
@@ -44,6 +45,7 @@ def load() -> C.CDLL:
     u64, i32, f64 = C.c_uint64, C.c_int, C.c_double
     p_u64, p_f64, vp = C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_void_p
     pp = C.POINTER(C.c_void_p)
+    p_i32 = C.POINTER(C.c_int)
 
     def sig(name, res, args):
         f = getattr(L, name)
@@ -80,6 +82,13 @@ def load() -> C.CDLL:
     sig("vl_last_path", i32, [])
     sig("vl_index_force_path", i32, [vp, i32])
     sig("vl_index_set_single_filter", i32, [vp, i32])
+    sig("vl_vlc_open", i32, [C.c_char_p, C.POINTER(vp)])
+    sig("vl_vlc_close", None, [vp])
+    sig("vl_vlc_name", C.c_char_p, [vp])
+    sig("vl_vlc_info", i32, [vp, p_i32, p_i32, p_u64, p_u64, p_u64, p_u64])
+    sig("vl_vlc_side_table", i32, [vp, p_u64, p_u64, p_u64, p_u64, p_u64])
+    sig("vl_vlc_read_values", i32, [vp, u64, u64, p_f64])
+    sig("vl_vlc_build_index", i32, [vp, i32, C.POINTER(vp)])
     sig("vl_index_set_coalescing", i32, [vp, i32, i32])
     sig("vl_index_coalesce_stats", i32, [vp, p_u64, p_u64])
     sig("vl_index_profile_enable", i32, [vp, i32])

@@ -7,6 +7,7 @@
 
 #include "flat_index.hpp"
 #include "hnsw_index.hpp"
+#include "vlc_loader.hpp"
 
 // enum VectorIndexWrapper { Flat(FlatIndex), HNSW(Box<HNSWIndex>) } (src/lib.rs:271-276): exactly one
 // of the two pointers is set; the vl_index_* entry points dispatch like the wrapper's impl
@@ -282,6 +283,80 @@ int vl_index_hnsw_distances(const vl_index* h, const double* query, uint64_t q_l
 // convert_distance_to_similarity(d as f64 / 1000.0, metric): src/index/hnsw.rs:51-75, :478-479.
 // Four scalar operations on the k winners' u64 distances; no vector data is touched here.
 double vl_hnsw_score(uint64_t d_u64, int metric) { return vl::hnsw_score(d_u64, metric); }
+
+struct vl_vlc_doc {
+    vl::VlcDoc* d;
+};
+
+int vl_vlc_open(const char* path, vl_vlc_doc** out)
+{
+    return guarded([&]() -> int {
+        if (!path || !out) return VL_ERR_INVALID_ARG;
+        *out = nullptr;
+        vl::VlcDoc* d = nullptr;
+        const int rc = vl::vlc_open(path, &d);
+        if (rc != VL_OK) return rc;
+        vl_vlc_doc* h = new (std::nothrow) vl_vlc_doc{d};
+        if (!h) {
+            vl::vlc_close(d);
+            return VL_ERR_OOM;
+        }
+        *out = h;
+        return VL_OK;
+    });
+}
+
+void vl_vlc_close(vl_vlc_doc* doc)
+{
+    if (!doc) return;
+    vl::vlc_close(doc->d);
+    delete doc;
+}
+
+const char* vl_vlc_name(const vl_vlc_doc* doc) { return doc ? vl::vlc_name(doc->d) : ""; }
+
+int vl_vlc_info(const vl_vlc_doc* doc, int* index_type, int* metric, uint64_t* dim, uint64_t* rows, uint64_t* vector_count,
+                uint64_t* dimension)
+{
+    if (!doc) return VL_ERR_INVALID_ARG;
+    vl::vlc_info(doc->d, index_type, metric, dim, rows, vector_count, dimension);
+    return VL_OK;
+}
+
+int vl_vlc_side_table(const vl_vlc_doc* doc, uint64_t* ids, uint64_t* text_off, uint64_t* text_len, uint64_t* meta_off,
+                      uint64_t* meta_len)
+{
+    if (!doc) return VL_ERR_INVALID_ARG;
+    return vl::vlc_side_table(doc->d, ids, text_off, text_len, meta_off, meta_len);
+}
+
+int vl_vlc_read_values(const vl_vlc_doc* doc, uint64_t first, uint64_t n, double* out_values)
+{
+    return guarded([&]() -> int {
+        if (!doc) return VL_ERR_INVALID_ARG;
+        return vl::vlc_read_values(doc->d, first, n, out_values);
+    });
+}
+
+int vl_vlc_build_index(const vl_vlc_doc* doc, int device, vl_index** out)
+{
+    return guarded([&]() -> int {
+        if (!doc || !out) return VL_ERR_INVALID_ARG;
+        *out = nullptr;
+        vl::GpuFlatIndex* f = nullptr;
+        vl::HnswIndex* hn = nullptr;
+        const int rc = vl::vlc_build_index(doc->d, device, &f, &hn);
+        if (rc != VL_OK) return rc;
+        vl_index* h = new (std::nothrow) vl_index{f, hn};
+        if (!h) {
+            delete f;
+            delete hn;
+            return VL_ERR_OOM;
+        }
+        *out = h;
+        return VL_OK;
+    });
+}
 
 const char* vl_last_error(void) { return vl::last_error(); }
 void vl_last_dim_mismatch(uint64_t* expected, uint64_t* actual) { vl::get_dim_mismatch(expected, actual); }
