@@ -90,7 +90,9 @@ int vl_hnsw_create(uint64_t dim, int metric, int device, vl_index **out);
 int vl_hnsw_create_ex(uint64_t dim, int metric, uint32_t m, uint32_t m0, uint32_t ef_construction, uint64_t seed,
                       int device, vl_index **out);
 
-/* #[derive(Clone)] (src/index/flat.rs:59; persistence clones the index, src/persistence.rs:118). */
+/* #[derive(Clone)] (src/index/flat.rs:59, src/index/hnsw.rs:197; persistence clones the wrapper,
+ * src/persistence.rs:118).  Flat: rows copied device to device.  HNSW: rows and the device graph are
+ * copied as they are (tombstoned nodes included), so the clone answers exactly like the original. */
 int vl_index_clone(const vl_index *h, vl_index **out);
 
 void vl_index_destroy(vl_index *h);
@@ -148,7 +150,8 @@ int vl_index_get_vector(const vl_index *h, uint64_t id, double *out_values);
 /* max_id() (src/index/flat.rs:76-78): VL_ERR_NOT_FOUND stands for None (empty index). */
 int vl_index_max_id(const vl_index *h, uint64_t *out_id);
 
-/* Rows in storage order, for Serialize (src/index/flat.rs:59): ids[len], values[len, dim]. */
+/* Rows in storage order, for Serialize (src/index/flat.rs:59): ids[len], values[len, dim].
+ * HNSW handle: the live rows in insertion order (the `vector_values` member, src/index/hnsw.rs:197-214). */
 int vl_index_export(const vl_index *h, uint64_t *out_ids, double *out_values);
 
 /* ---- .vlc collection files (src/persistence.rs:149-176; the step before the path) --------- */

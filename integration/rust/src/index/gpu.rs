@@ -262,6 +262,78 @@ impl GpuHnswIndex {
     }
 }
 
+/// Same on-disk payload as the CPU `HNSWIndex` (`src/index/hnsw.rs:197-214`); its custom Deserialize only
+/// reads `dim`, `metric`, `metadata` and `vector_values` (`:277-283`), so the two id maps are written as the
+/// identity over the live rows.
+#[derive(Serialize, Deserialize)]
+struct HnswMeta {
+    text: String,
+    metadata: Option<serde_json::Value>,
+}
+#[derive(Serialize)]
+struct HnswPayloadOut {
+    dim: usize,
+    metric: SimilarityMetric,
+    id_to_index: HashMap<u64, usize>,
+    index_to_id: HashMap<usize, u64>,
+    metadata: HashMap<u64, HnswMeta>,
+    vector_values: HashMap<u64, Vec<f64>>,
+}
+#[derive(Deserialize)]
+struct HnswPayloadIn {
+    dim: usize,
+    metric: SimilarityMetric,
+    metadata: HashMap<u64, HnswMeta>,
+    vector_values: HashMap<u64, Vec<f64>>,
+}
+
+impl Serialize for GpuHnswIndex {
+    fn serialize<S: Serializer>(&self, s: S) -> Result<S::Ok, S::Error> {
+        let (ids, values) = self.h.export();
+        let dim = self.h.dim;
+        let mut out = HnswPayloadOut {
+            dim,
+            metric: self.metric,
+            id_to_index: HashMap::new(),
+            index_to_id: HashMap::new(),
+            metadata: HashMap::new(),
+            vector_values: HashMap::new(),
+        };
+        for (i, &id) in ids.iter().enumerate() {
+            let (text, metadata) = self.h.side.get(&id).cloned().unwrap_or_default();
+            out.id_to_index.insert(id, i);
+            out.index_to_id.insert(i, id);
+            out.metadata.insert(id, HnswMeta { text, metadata });
+            out.vector_values.insert(id, values[i * dim..(i + 1) * dim].to_vec());
+        }
+        out.serialize(s)
+    }
+}
+
+impl<'de> Deserialize<'de> for GpuHnswIndex {
+    fn deserialize<D: Deserializer<'de>>(d: D) -> Result<Self, D::Error> {
+        let p = HnswPayloadIn::deserialize(d)?;
+        if p.dim == 0 {
+            return Err(serde::de::Error::custom("Invalid dimension: cannot be 0"));
+        }
+        let mut idx = GpuHnswIndex::new(p.dim, p.metric);
+        let mut ids = Vec::with_capacity(p.vector_values.len());
+        let mut values = Vec::with_capacity(p.vector_values.len() * p.dim);
+        for (id, v) in &p.vector_values {
+            if v.len() != p.dim {
+                return Err(serde::de::Error::custom(format!("Vector dimension mismatch: expected {}, got {}", p.dim, v.len())));
+            }
+            ids.push(*id);
+            values.extend_from_slice(v);
+        }
+        idx.add_all(&ids, &values).map_err(serde::de::Error::custom)?;
+        for (id, m) in p.metadata {
+            idx.h.side.insert(id, (m.text, m.metadata));
+        }
+        Ok(idx)
+    }
+}
+
 impl VectorIndex for GpuHnswIndex {
     fn add(&mut self, vector: Vector) -> Result<(), String> {
         self.h.add(vector)

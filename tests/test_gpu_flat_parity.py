@@ -109,6 +109,29 @@ def test_random_parity_all_metrics(V, O, dim):
                     assert_same(V, gpu.search_arrays(q, k, m), ref.search(q, k, m), (dim, n, name, k))
 
 
+@pytest.mark.parametrize("dim", [1000, 1024, 1536, 2048, 3072, 4096, 5000])
+def test_large_dims_parity(V, O, dim):
+    """Embedding sizes beyond the benchmark's 384 / 768 (specialised and generic scan shapes, the
+    finalize kernel's chunked f64 rescoring): singles, an 8-query batch, and the forced exact path."""
+    rng = np.random.default_rng(dim)
+    n = 1500
+    rows = unit_rows(rng, n, dim)
+    ids = permuted_ids(n)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    Q = unit_rows(rng, 9, dim)
+    for name, m in M.items():
+        assert_same(V, gpu.search_arrays(Q[0], 10, m), ref.search(Q[0], 10, m), (dim, name))
+        assert V.last_path() == V.PATH_FAST
+    bi, bs, bn = gpu.search_batch(Q, 10, M["cosine"])
+    for j in range(9):
+        want = ref.search(Q[j], 10, M["cosine"])
+        assert bi[j, : bn[j]].tolist() == want[0].tolist() and bs[j, : bn[j]].tolist() == want[1].tolist()
+    gpu.force_path(V.PATH_EXACT_SELECT)
+    assert_same(V, gpu.search_arrays(Q[1], 10, M["euclidean"]), ref.search(Q[1], 10, M["euclidean"]), (dim, "exact"))
+
+
 def test_fast_path_is_the_one_running(V, O):
     rng = np.random.default_rng(99)
     n, dim = 20000, 384

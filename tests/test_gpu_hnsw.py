@@ -165,3 +165,32 @@ def test_incremental_adds_match_bulk_semantics(V, O):
     with pytest.raises(V.IndexOpError):
         idx.add_rows([5000, 7], rows[:2])  # second id exists: first row is kept, like sequential adds
     assert len(idx) == n + 1
+
+
+def test_clone_and_export_keep_graph_and_tombstones(V):
+    """#[derive(Clone)] on HNSWIndex (persistence clones the wrapper, src/persistence.rs:118): the copy
+    answers like the original, tombstones included, and then lives its own life."""
+    rng = np.random.default_rng(21)
+    n, dim = 4000, 32
+    z = rng.standard_normal((n, 6)) @ rng.standard_normal((6, dim))
+    idx = V.HNSWIndex(dim, V.SimilarityMetric.Euclidean)
+    ids = np.arange(n, dtype=np.uint64) * 5 + 2
+    idx.add_rows(ids, z)
+    for i in (0, 17, 900):
+        idx.delete(int(ids[i]))
+    c = idx.clone()
+    assert len(c) == len(idx) == n - 3 and c.metric() == idx.metric() and c.dimension() == dim
+    Q = z[rng.integers(0, n, 40)] + 0.01
+    a = idx.search_batch(Q, 10, V.SimilarityMetric.Euclidean, ef=64)
+    b = c.search_batch(Q, 10, V.SimilarityMetric.Euclidean, ef=64)
+    assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist() and a[2].tolist() == b[2].tolist()
+    ei, ev = c.export()
+    keep = np.ones(n, bool)
+    keep[[0, 17, 900]] = False
+    assert ei.tolist() == ids[keep].tolist() and np.array_equal(ev, z[keep])
+    c.delete(int(ids[5]))
+    c.add(V.Vector(10**9, z[5] * 1.5, "new"))
+    assert len(idx) == n - 3 and len(c) == n - 3
+    assert idx.get_vector(int(ids[5])) is not None and c.get_vector(int(ids[5])) is None
+    with pytest.raises(V.IndexOpError):
+        c.delete(int(ids[17]))  # the tombstone came along: "does not exist"

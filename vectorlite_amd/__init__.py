@@ -397,6 +397,22 @@ class HNSWIndex:
                 pass
             self._h = None
 
+    def clone(self) -> "HNSWIndex":
+        """Deep copy (rows + device graph, tombstones included): #[derive(Clone)] on HNSWIndex."""
+        h = C.c_void_p()
+        _raise(self._L.vl_index_clone(self._h, C.byref(h)))
+        c = HNSWIndex(self.dimension(), device=self.device, _handle=h)
+        c._meta = dict(self._meta)
+        return c
+
+    def export(self) -> Tuple[np.ndarray, np.ndarray]:
+        """(ids, values) of the live rows in insertion order: the serialised `vector_values`."""
+        n, d = self.len(), self.dimension()
+        ids = np.empty(max(n, 1), dtype=np.uint64)
+        vals = np.empty((max(n, 1), max(d, 1)), dtype=np.float64)
+        _raise(self._L.vl_index_export(self._h, _pu64(ids), _pf64(vals)))
+        return ids[:n].copy(), vals[:n, :d].copy()
+
     def metric(self) -> SimilarityMetric:
         m = C.c_int(0)
         _raise(self._L.vl_index_metric(self._h, C.byref(m)))

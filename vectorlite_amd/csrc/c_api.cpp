@@ -120,9 +120,20 @@ int vl_hnsw_create(uint64_t dim, int metric, int device, vl_index** out)
 int vl_index_clone(const vl_index* h, vl_index** out)
 {
     return guarded([&]() -> int {
-        VL_FLAT_ONLY(h);
         if (!h || !out) return VL_ERR_INVALID_ARG;
         *out = nullptr;
+        if (h->hnsw) {
+            vl::HnswIndex* hc = nullptr;
+            int rc = h->hnsw->clone(&hc);
+            if (rc != VL_OK) return rc;
+            vl_index* w = new (std::nothrow) vl_index{nullptr, hc};
+            if (!w) {
+                delete hc;
+                return VL_ERR_OOM;
+            }
+            *out = w;
+            return VL_OK;
+        }
         vl::GpuFlatIndex* c = nullptr;
         int rc = h->flat->clone(&c);
         if (rc != VL_OK) return rc;
@@ -266,7 +277,8 @@ int vl_index_max_id(const vl_index* h, uint64_t* out_id)
 int vl_index_export(const vl_index* h, uint64_t* out_ids, double* out_values)
 {
     return guarded([&]() -> int {
-        VL_FLAT_ONLY(h);
+        if (!h) return VL_ERR_INVALID_ARG;
+        if (h->hnsw) return h->hnsw->export_rows(out_ids, out_values);
         return h->flat->export_rows(out_ids, out_values);
     });
 }

@@ -317,6 +317,69 @@ int HnswIndex::get_vector(uint64_t id, double* out) const
     return OK;
 }
 
+int HnswIndex::clone(HnswIndex** out) const
+{
+    if (!out) return ERR_INVALID_ARG;
+    *out = nullptr;
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    VL_HIP(hipSetDevice(device_));
+    std::unique_ptr<HnswIndex> c(new HnswIndex(dim_, metric_, params_, device_));
+    GpuFlatIndex* st = nullptr;
+    VL_TRY(store_->clone(&st));
+    c->store_.reset(st);
+    VL_HIP(hipStreamCreateWithFlags(&c->stream_, hipStreamNonBlocking));
+    if (n_nodes_) {
+        VL_TRY(c->ensure_graph(n_nodes_, n_upper_));
+        auto copy = [&](void* dst, const void* src, size_t bytes) -> int {
+            if (bytes) VL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream_));
+            return OK;
+        };
+        VL_TRY(copy(c->d_nbr0_, d_nbr0_, n_nodes_ * params_.m0 * sizeof(uint32_t)));
+        VL_TRY(copy(c->d_dist0_, d_dist0_, n_nodes_ * params_.m0 * sizeof(unsigned long long)));
+        VL_TRY(copy(c->d_cnt0_, d_cnt0_, n_nodes_ * sizeof(uint32_t)));
+        VL_TRY(copy(c->d_level_, d_level_, n_nodes_ * sizeof(uint8_t)));
+        VL_TRY(copy(c->d_upper_off_, d_upper_off_, n_nodes_ * sizeof(uint32_t)));
+        VL_TRY(copy(c->d_nbrU_, d_nbrU_, n_upper_ * params_.m * sizeof(uint32_t)));
+        VL_TRY(copy(c->d_distU_, d_distU_, n_upper_ * params_.m * sizeof(unsigned long long)));
+        VL_TRY(copy(c->d_cntU_, d_cntU_, n_upper_ * sizeof(uint32_t)));
+        VL_HIP(hipStreamSynchronize(c->stream_));
+    }
+    c->level_ = level_;
+    c->upper_off_ = upper_off_;
+    c->n_upper_ = n_upper_;
+    c->entry_ = entry_;
+    c->max_level_ = max_level_;
+    c->n_nodes_ = n_nodes_;
+    c->id_to_node_ = id_to_node_;
+    c->node_id_ = node_id_;
+    c->live_ = live_;
+    c->live_count_ = live_count_;
+    *out = c.release();
+    return OK;
+}
+
+int HnswIndex::export_rows(uint64_t* out_ids, double* out_values) const
+{
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    if (live_count_ == 0) return OK;
+    if (!out_ids || !out_values) return ERR_INVALID_ARG;
+    VL_HIP(hipSetDevice(device_));
+    uint64_t w = 0;
+    for (uint64_t node = 0; node < n_nodes_;) {  // copy maximal runs of live nodes
+        if (!live_[node]) {
+            ++node;
+            continue;
+        }
+        uint64_t e = node;
+        while (e < n_nodes_ && live_[e]) ++e;
+        VL_HIP(hipMemcpy(out_values + w * dim_, store_->device_master() + node * dim_, (e - node) * dim_ * sizeof(double),
+                         hipMemcpyDeviceToHost));
+        for (uint64_t i = node; i < e; ++i) out_ids[w++] = node_id_[i];
+        node = e;
+    }
+    return OK;
+}
+
 int HnswIndex::max_id(uint64_t* out) const
 {
     std::shared_lock<std::shared_mutex> lk(mu_);

@@ -44,6 +44,11 @@ public:
     int get_vector(uint64_t id, double* out) const;
     int max_id(uint64_t* out) const;
     uint64_t graph_nodes() const { return n_nodes_; }
+    // #[derive(Clone)] on HNSWIndex (persistence clones the wrapper, src/persistence.rs:118): a deep copy of
+    // the rows and of the device graph, tombstones included.
+    int clone(HnswIndex** out) const;
+    // live rows in node (insertion) order: the `vector_values` member of the serialised form
+    int export_rows(uint64_t* out_ids, double* out_values) const;
 
 private:
     HnswIndex(uint64_t dim, int metric, const HnswParams& p, int device);

@@ -211,10 +211,10 @@ def payload_from_index(index) -> Tuple[str, dict]:
             rows.append({"id": i, "values": v, "text": text, "metadata": md})
         return "Flat", {"Flat": {"dim": index.dimension(), "data": rows}}
     if isinstance(index, HNSWIndex):
-        ids = sorted(index._meta.keys()) if index._meta else []
-        live = [i for i in ids if index.get_vector(i) is not None]
-        vv = {str(i): index.get_vector(i).values for i in live}
-        md = {str(i): {"text": index._meta[i][0], "metadata": index._meta[i][1]} for i in live}
+        ids, vals = index.export()  # live rows, insertion order
+        live = ids.tolist()
+        vv = {str(i): v for i, v in zip(live, vals.tolist())}
+        md = {str(i): {"text": index._meta.get(i, ("", None))[0], "metadata": index._meta.get(i, ("", None))[1]} for i in live}
         n2i = {str(i): n for n, i in enumerate(live)}
         return "HNSW", {"HNSW": {"dim": index.dimension(), "metric": index.metric().name,
                                  "id_to_index": n2i, "index_to_id": {str(n): i for n, i in enumerate(live)},
