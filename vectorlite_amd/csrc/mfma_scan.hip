@@ -49,7 +49,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
                                                    const __bf16* __restrict__ q16, uint32_t nq, uint32_t n_tiles,
                                                    uint32_t n_rows, int* __restrict__ gmax, uint32_t n_groups,
                                                    const float* __restrict__ thr, Cand32* __restrict__ cand,
-                                                   uint32_t* __restrict__ cnt, uint32_t cap)
+                                                   uint32_t* __restrict__ cnt, uint32_t cap, uint32_t tile_begin)
 {
     constexpr int LDB = KSTEPS * 16;            // bf16 elements per row
     constexpr int ROW_BYTES = LDB * 2;
@@ -70,8 +70,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
     __shared__ float ring_key[RING];
     __shared__ uint32_t ring_pos[RING];
     __shared__ unsigned short ring_q[RING];
-    __shared__ uint32_t ring_cnt;
-    if (threadIdx.x == 0) ring_cnt = 0;
+    // Every wave owns one segment of the ring and counts its entries in a wave-uniform register:
+    // appending a candidate needs no atomic and no other wave (see the epilogue).
+    constexpr int SEG = RING / NWAVES > 0 ? RING / NWAVES : 1;
+    __shared__ uint32_t wave_cnt[NWAVES];
+    uint32_t my_cnt = 0;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
     // tile schedule: workgroup x takes tiles x, x + gridDim.x, ... in both modes, so neighbouring
     // workgroups stream neighbouring tiles.  In MODE 0 that residue class is the workgroup's "group":
     // its maximum belongs to rows no other group holds.
-    uint32_t t = blockIdx.x;
+    uint32_t t = tile_begin + blockIdx.x;  // MODE 1 runs in stages over [tile_begin, n_tiles)
     const uint32_t t_end = n_tiles, t_step = gridDim.x;
 
     float thr_q[QT], run_max[QT];
@@ -162,27 +165,29 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
     int buf = 0;
     // Ring flush: the only global atomics of the kernel.  It runs at trip boundaries (where hipcc
     // drains vmcnt anyway) when the ring is half full, and once after the loop.
-    auto flush_ring = [&]() {
-        __syncthreads();
-        const uint32_t total = ring_cnt;
-        const uint32_t n_ring = total < (uint32_t)RING ? total : (uint32_t)RING;
-        for (uint32_t i = tid; i < n_ring; i += NT) {
-            const uint32_t qq = blockIdx.y * MF_QPB + ring_q[i];
-            const uint32_t slot = atomicAdd(&cnt[qq], 1u);
-            if (slot < cap) {
-                Cand32 e;
-                e.key = ring_key[i];
-                e.pos = ring_pos[i];
-                cand[(size_t)qq * cap + slot] = e;
+    auto flush_ring = [&]() {  // caller has published wave_cnt[] and passed a barrier
+        bool overflow = false;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) overflow = overflow || wave_cnt[w] > (uint32_t)SEG;
+        for (uint32_t e = tid; e < (uint32_t)(NWAVES * SEG); e += NT) {
+            const uint32_t w = e / SEG, i = e % SEG;
+            if (i < wave_cnt[w]) {
+                const uint32_t qq = blockIdx.y * MF_QPB + ring_q[e];
+                const uint32_t slot = atomicAdd(&cnt[qq], 1u);
+                if (slot < cap) {
+                    Cand32 c;
+                    c.key = ring_key[e];
+                    c.pos = ring_pos[e];
+                    cand[(size_t)qq * cap + slot] = c;
+                }
             }
         }
-        if (total > (uint32_t)RING && tid < MF_QPB) {  // ring overflow: these queries are redone by the host
+        if (overflow && tid < MF_QPB) {  // a segment overflowed: these queries are redone by the host
             const uint32_t qq = blockIdx.y * MF_QPB + tid;
             if (qq < nq) atomicAdd(&cnt[qq], cap + 1u);
         }
-        __syncthreads();
-        if (tid == 0) ring_cnt = 0;
-        __syncthreads();
+        my_cnt = 0;
+        __syncthreads();  // everyone is done reading wave_cnt[] and the ring before they are reused
     };
     // hipcc drains the ring (vmcnt(0)) at the loop header but uses counted waits inside straight-line
     // code, so one trip covers UNROLL * DEPTH tiles: one drain per 16 tiles instead of one per 4.
@@ -267,20 +272,37 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
                         if (!tile_live || row0 + (uint32_t)((reg & 3) + 8 * (reg >> 2) + 4 * half) >= n_rows)
                             keys[reg] = -INFINITY;
                 }
-                float m = fmaxf(keys[0], keys[1]);
+                float m4[4];
 #pragma unroll
-                for (int reg = 2; reg < 16; ++reg) m = fmaxf(m, keys[reg]);
+                for (int g4 = 0; g4 < 4; ++g4)
+                    m4[g4] = fmaxf(fmaxf(keys[4 * g4], keys[4 * g4 + 1]), fmaxf(keys[4 * g4 + 2], keys[4 * g4 + 3]));
+                const float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
                 if (MODE == 0) {
                     run_max[qt] = fmaxf(run_max[qt], m);
-                } else if (m >= thr_q[qt]) {
+                } else if (__builtin_amdgcn_ballot_w64(m >= thr_q[qt]) != 0ull) {
+                    // Rare per wave-tile, but the WHOLE workgroup waits for the slowest wave at the next
+                    // barrier, and with 8 waves some wave takes this branch on most tiles: it must be
+                    // short.  No atomic (the wave appends to its own ring segment), 4-register groups
+                    // without a candidate are skipped with one ballot, slots come from ballot + mbcnt.
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        if (keys[reg] >= thr_q[qt]) {
-                            const uint32_t slot = atomicAdd(&ring_cnt, 1u);  // LDS atomic
-                            if (slot < (uint32_t)RING) {
-                                ring_key[slot] = keys[reg];
-                                ring_pos[slot] = row0 + (uint32_t)((reg & 3) + 8 * (reg >> 2) + 4 * half);
-                                ring_q[slot] = (unsigned short)((wave * QT + qt) * 32 + col);
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        if (__builtin_amdgcn_ballot_w64(m4[g4] >= thr_q[qt]) == 0ull) continue;  // wave-uniform
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int reg = 4 * g4 + jj;
+                            const bool is_cand = keys[reg] >= thr_q[qt];
+                            const unsigned long long mk = __builtin_amdgcn_ballot_w64(is_cand);
+                            if (mk != 0ull) {  // wave-uniform
+                                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32),
+                                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                                const uint32_t slot = my_cnt + rank;
+                                if (is_cand && slot < (uint32_t)SEG) {
+                                    const uint32_t e = (uint32_t)wave * SEG + slot;
+                                    ring_key[e] = keys[reg];
+                                    ring_pos[e] = row0 + (uint32_t)((reg & 3) + 8 * (reg >> 2) + 4 * half);
+                                    ring_q[e] = (unsigned short)((wave * QT + qt) * 32 + col);
+                                }
+                                my_cnt += (uint32_t)__popcll(mk);
                             }
                         }
                     }
@@ -293,12 +315,21 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
             // in its epilogue to stop it)
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (MODE == 1) {
+        if (MODE == 1) {  // trip boundary: flush when some wave's segment is half full (workgroup-uniform decision)
+            if (lane == 0) wave_cnt[wave] = my_cnt;
             __syncthreads();
-            if (ring_cnt >= (uint32_t)(RING / 2)) flush_ring();  // workgroup-uniform
+            uint32_t fullest = 0;
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) fullest = wave_cnt[w] > fullest ? wave_cnt[w] : fullest;
+            if (fullest >= (uint32_t)(SEG / 2)) flush_ring();
+            else __syncthreads();  // wave_cnt[] is rewritten at the next boundary
         }
     }
-    if (MODE == 1) flush_ring();  // whatever the last trips left behind
+    if (MODE == 1) {  // whatever the last trips left behind
+        if (lane == 0) wave_cnt[wave] = my_cnt;
+        __syncthreads();
+        flush_ring();
+    }
     if (MODE == 0) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
@@ -444,6 +475,33 @@ __global__ __launch_bounds__(256) void k_select_candidates(const Cand32* __restr
     }
 }
 
+// Between two stages of pass 1: T_q = max(T_q, 64th largest key among the candidates found so far).
+// Those are 64 distinct rows, so the value is still a lower bound of the query's 64th best key, and it
+// is much tighter than the sampling bound: the later stages (most of the rows) take the candidate branch
+// of k_mfma_scan's epilogue a few times less often.  One wave per query.
+__global__ __launch_bounds__(256) void k_refine_thresholds(const Cand32* __restrict__ cand, const uint32_t* __restrict__ cnt,
+                                                          uint32_t cap, uint32_t nq, float* __restrict__ thr)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const uint32_t n = cnt[q];
+    if (n < 64u || n > cap) return;  // too few to say anything / overflowed (the host redoes that query)
+    TopList<float> L;
+    L.init();
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const bool ok = i < n;
+        Cand32 e;
+        e.key = 0.f;
+        e.pos = 0;
+        if (ok) e = cand[(size_t)q * cap + i];
+        L.offer(e.key, e.pos, ok);
+    }
+    const float t64 = read_lane(L.key, 63);
+    if (lane == 0 && t64 > thr[q]) thr[q] = t64;
+}
+
 // f64 queries -> bf16 [nq_pad, ldb] (zero padded rows and columns), rounded f64 -> f32 -> bf16 (RNE).
 __global__ void k_queries_bf16(const double* __restrict__ q64, uint32_t nq, uint32_t nq_pad, uint32_t dim,
                                uint32_t ldb, __bf16* __restrict__ out)
@@ -572,17 +630,37 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     // sequence, so a tile is fetched from HBM once and served to the other chunks by L2 / Infinity Cache
     const uint32_t n_chunks = nq_pad / qpb;
     const int pass1_blocks = (int)std::min<uint32_t>(n_tiles, (uint32_t)env_grid(n_chunks));
-    const dim3 grid1(pass1_blocks, nq_pad / qpb);
+    // Pass 1 runs in stages of growing size (3/16, 4/16, 9/16 of the tiles); between stages the thresholds
+    // are tightened from the candidates found so far (k_refine_thresholds).  Short scans keep one stage.
+    uint32_t stage_end[4] = {0, n_tiles, n_tiles, n_tiles};
+    int n_stages = 1;
+    {
+        const char* se = getenv("VL_MFMA_STAGES");
+        const int want = se && *se ? atoi(se) : 3;
+        if (want >= 2 && n_tiles >= 64u * (uint32_t)pass1_blocks) {
+            n_stages = want >= 3 ? 3 : 2;
+            stage_end[1] = (uint32_t)((uint64_t)n_tiles * 3 / 16);
+            stage_end[2] = n_stages == 3 ? (uint32_t)((uint64_t)n_tiles * 7 / 16) : n_tiles;
+            stage_end[3] = n_tiles;
+        }
+    }
 
     bool launched = false;
 #define VL_LAUNCH3(K, MET, NW, QTT)                                                                                     \
     {                                                                                                                   \
         hipLaunchKernelGGL((k_mfma_scan<K, 0, MET, NW, QTT>), grid0, dim3(NW * 64), 0, s, slab, row_norm, row_sqnorm, q16, nq,       \
                            sample_tiles, (uint32_t)sample_rows, w.gmax, n_groups, (const float*)nullptr,               \
-                           (Cand32*)nullptr, (uint32_t*)nullptr, 0u);                                                   \
+                           (Cand32*)nullptr, (uint32_t*)nullptr, 0u, 0u);                                               \
         hipLaunchKernelGGL(k_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.gmax, n_groups, nq, w.thr);             \
-        hipLaunchKernelGGL((k_mfma_scan<K, 1, MET, NW, QTT>), grid1, dim3(NW * 64), 0, s, slab, row_norm, row_sqnorm, q16, nq,       \
-                           n_tiles, (uint32_t)n_rows, (int*)nullptr, 0u, w.thr, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP); \
+        for (int st = 0; st < n_stages; ++st) {                                                                         \
+            const uint32_t tb = stage_end[st], te = stage_end[st + 1];                                                  \
+            const dim3 grid1((uint32_t)std::min<uint32_t>(te - tb, (uint32_t)pass1_blocks), nq_pad / qpb);              \
+            hipLaunchKernelGGL((k_mfma_scan<K, 1, MET, NW, QTT>), grid1, dim3(NW * 64), 0, s, slab, row_norm, row_sqnorm, q16, nq,   \
+                               te, (uint32_t)n_rows, (int*)nullptr, 0u, w.thr, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, tb); \
+            if (st + 1 < n_stages)                                                                                      \
+                hipLaunchKernelGGL(k_refine_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.cand, w.cnt,             \
+                                   (uint32_t)MFMA_CAND_CAP, nq, w.thr);                                                 \
+        }                                                                                                               \
         launched = true;                                                                                                \
     }
 #define VL_LAUNCH2(K, MET)                                        \
