@@ -533,51 +533,61 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan_dma(const __bf16* __r
         lds_barrier();
     };
 
-    // epilogue of one finished tile (same arithmetic as k_mfma_scan)
-    auto epilogue = [&](const f32x16(&acc)[QT], uint32_t tile, bool live, uint32_t b) {
+    // Epilogue of one finished tile, cut into five steps that the main loop issues BETWEEN the MFMA groups
+    // of the next tile (each step is a handful of VALU operations that execute in the shadow of the MFMAs
+    // just issued; as one block after the tile they cost 19 % of the kernel):
+    //   steps 0..3: the four keys of register group g4 -> their maximum m4[qt][g4];
+    //   step 4:     m = max(m4), MODE 0: running maximum; MODE 1: compare with T_q and, rarely, the hit path
+    //               (which recomputes the keys it needs from the accumulators).
+    auto key_of = [&](const f32x16& a, int reg, const f32x4& nr, const f32x4& sq) -> float {
+        float key = a[reg];                                                  // cosine: x^.q
+        if (METRIC == DOT) key *= nr[reg & 3];                               // x.q
+        if (METRIC == EUCLIDEAN) key = 2.0f * key * nr[reg & 3] - sq[reg & 3];  // |q|^2 - |x - q|^2
+        return key;
+    };
+    auto masked = [&](float key, int reg, uint32_t row0, bool live) -> float {
+        return (!live || row0 + (uint32_t)((reg & 3) + 8 * (reg >> 2) + 4 * half) >= n_rows) ? -INFINITY : key;
+    };
+    float m4[QT][4];
+    auto epi_slice = [&](const f32x16(&acc)[QT], int g4, uint32_t tile, bool live, uint32_t b) {
         const uint32_t row0 = tile * MF_ROWS;
-        f32x4 aux[4], aux2[4];
-        if (METRIC != COSINE) {
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) aux[g4] = *reinterpret_cast<const f32x4*>(aux_nrm + b * 64 + 8 * g4 + 4 * half);
-        }
-        if (METRIC == EUCLIDEAN) {
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) aux2[g4] = *reinterpret_cast<const f32x4*>(aux_sqn + b * 64 + 8 * g4 + 4 * half);
-        }
+        const bool partial = row0 + MF_ROWS > n_rows || !live;  // wave-uniform
+        f32x4 nr = {1.f, 1.f, 1.f, 1.f}, sq = {0.f, 0.f, 0.f, 0.f};
+        if (METRIC != COSINE) nr = *reinterpret_cast<const f32x4*>(aux_nrm + b * 64 + 8 * g4 + 4 * half);
+        if (METRIC == EUCLIDEAN) sq = *reinterpret_cast<const f32x4*>(aux_sqn + b * 64 + 8 * g4 + 4 * half);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            float keys[16];
+            float k4[4];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    float key = acc[qt][4 * g4 + jj];
-                    if (METRIC == DOT) key *= aux[g4][jj];
-                    if (METRIC == EUCLIDEAN) key = 2.0f * key * aux[g4][jj] - aux2[g4][jj];
-                    keys[4 * g4 + jj] = key;
-                }
+            for (int jj = 0; jj < 4; ++jj) {
+                k4[jj] = key_of(acc[qt], 4 * g4 + jj, nr, sq);
+                if (partial) k4[jj] = masked(k4[jj], 4 * g4 + jj, row0, live);
             }
-            if (row0 + MF_ROWS > n_rows || !live) {  // partial last tile / masked tile (wave-uniform)
+            m4[qt][g4] = fmaxf(fmaxf(k4[0], k4[1]), fmaxf(k4[2], k4[3]));
+        }
+    };
+    auto epi_final = [&](const f32x16(&acc)[QT], uint32_t tile, bool live, uint32_t b) {
+        const uint32_t row0 = tile * MF_ROWS;
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg)
-                    if (!live || row0 + (uint32_t)((reg & 3) + 8 * (reg >> 2) + 4 * half) >= n_rows) keys[reg] = -INFINITY;
-            }
-            float m4[4];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-                m4[g4] = fmaxf(fmaxf(keys[4 * g4], keys[4 * g4 + 1]), fmaxf(keys[4 * g4 + 2], keys[4 * g4 + 3]));
-            const float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+        for (int qt = 0; qt < QT; ++qt) {
+            const float m = fmaxf(fmaxf(m4[qt][0], m4[qt][1]), fmaxf(m4[qt][2], m4[qt][3]));
             if (MODE == 0) {
                 run_max[qt] = fmaxf(run_max[qt], m);
             } else if (__builtin_amdgcn_ballot_w64(m >= thr_q[qt]) != 0ull) {
+                // Rare per wave-tile, but the whole workgroup waits for the slowest wave at the next barrier:
+                // no atomic (the wave appends to its own ring segment), register groups without a candidate
+                // are skipped with one ballot, slots come from ballot + mbcnt.
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    if (__builtin_amdgcn_ballot_w64(m4[g4] >= thr_q[qt]) == 0ull) continue;  // wave-uniform
+                    if (__builtin_amdgcn_ballot_w64(m4[qt][g4] >= thr_q[qt]) == 0ull) continue;  // wave-uniform
+                    f32x4 nr = {1.f, 1.f, 1.f, 1.f}, sq = {0.f, 0.f, 0.f, 0.f};
+                    if (METRIC != COSINE) nr = *reinterpret_cast<const f32x4*>(aux_nrm + b * 64 + 8 * g4 + 4 * half);
+                    if (METRIC == EUCLIDEAN) sq = *reinterpret_cast<const f32x4*>(aux_sqn + b * 64 + 8 * g4 + 4 * half);
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
                         const int reg = 4 * g4 + jj;
-                        const bool is_cand = keys[reg] >= thr_q[qt] && keys[reg] > -INFINITY;  // masked rows are -inf; T_q may be too
+                        const float key = masked(key_of(acc[qt], reg, nr, sq), reg, row0, live);
+                        const bool is_cand = key >= thr_q[qt] && key > -INFINITY;  // masked rows are -inf; T_q may be too
                         const unsigned long long mk = __builtin_amdgcn_ballot_w64(is_cand);
                         if (mk != 0ull) {
                             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32),
@@ -585,7 +595,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan_dma(const __bf16* __r
                             const uint32_t slot = my_cnt + rank;
                             if (is_cand && slot < (uint32_t)SEG) {
                                 const uint32_t e = (uint32_t)wave * SEG + slot;
-                                ring_key[e] = keys[reg];
+                                ring_key[e] = key;
                                 ring_pos[e] = row0 + (uint32_t)((reg & 3) + 8 * (reg >> 2) + 4 * half);
                                 ring_q[e] = (unsigned short)((wave * QT + qt) * 32 + col);
                             }
@@ -639,9 +649,17 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan_dma(const __bf16* __r
                 for (int qt = 0; qt < QT; ++qt)
                     acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[g & 1][jj], bfrag[qt][g * GS + jj], acc[qt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (g == 0) {  // the previous tile's epilogue runs in the shadow of the MFMAs just issued
-                epilogue(acc_prev, tile_prev, live_prev, b_prev);
-                __builtin_amdgcn_sched_barrier(0);
+            // The previous tile's epilogue, spread over the MFMA groups: step e goes behind group e * SPAN / 5.
+            // Dot / Euclidean read the previous tile's row norms from its LDS buffer, which the middle block
+            // below hands to a new tile: their steps all sit at or before group MID.
+            constexpr int SPAN = (METRIC == COSINE) ? NG : MID + 1;
+#pragma unroll
+            for (int e = 0; e < 5; ++e) {
+                if (e * SPAN / 5 == g) {
+                    if (e < 4) epi_slice(acc_prev, e, tile_prev, live_prev, b_prev);
+                    else epi_final(acc_prev, tile_prev, live_prev, b_prev);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             if (g == MID) {
                 // tile i+1: my share has landed (D-1 younger tiles may still fly) -> barrier: everyone's has, and
@@ -668,7 +686,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan_dma(const __bf16* __r
             else lds_barrier();
         }
     }
-    epilogue(acc_prev, tile_prev, live_prev, b_prev);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) epi_slice(acc_prev, e, tile_prev, live_prev, b_prev);
+    epi_final(acc_prev, tile_prev, live_prev, b_prev);
     wait_vm<0>();  // the clamped tail tiles are still landing: nothing may be in flight when the LDS is released
     if (MODE == 1) {
         if (lane == 0) wave_cnt[wave] = my_cnt;
