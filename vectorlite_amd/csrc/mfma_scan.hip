@@ -341,371 +341,6 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_mfma_scan_dma: the same scan with the row tiles staged by LDS-DMA (global_load_lds_dwordx4).
-//
-// What the register-staged kernel above loses (measured: MFMA pipe 61 % busy with no candidates):
-// every tile step all 8 waves stop together to write their share of the tile to LDS, wait for the
-// writes, meet at the barrier and then wait out one LDS round trip for the first A fragments.
-// Here a tile goes HBM/L2 -> LDS without passing through registers, NB buffers deep:
-//   * one glds wave-instruction writes 1 KiB of LDS lane-linearly, so the tile image is unpadded; bank
-//     conflicts are avoided by an XOR swizzle applied on the SOURCE side (lane p of the image fetches
-//     chunk c' ^ (row & 15) of its row) and undone in the fragment read address;
-//   * the barrier that publishes tile i+1 sits in the MIDDLE of tile i's MFMA sequence (counted
-//     s_waitcnt vmcnt + raw s_barrier, never vmcnt(0)), so the first fragments of tile i+1 are fetched
-//     behind tile i's last MFMAs and the MFMA stream runs across tile boundaries;
-//   * the epilogue of tile i (max tree, threshold compare) is issued right after the first MFMA group
-//     of tile i+1 and executes in the shadow of those MFMAs.
-// Buffer rotation with NB = D + 2: at the middle of tile i, tile i+1 has landed (waited for), tiles
-// i+2..i+D are in flight, and tile i+D+1 is issued into the buffer of tile i-1, which every wave has
-// finished (it is past tile i's middle barrier).
-// ---------------------------------------------------------------------------------------------
-template <int KSTEPS, int MODE, int METRIC, int NWAVES>
-struct DmaCfg {
-    static constexpr int CPR = 2 * KSTEPS;                  // 16-byte chunks per row
-    static constexpr int ROW_BYTES = CPR * 16;
-    static constexpr int TILE_BYTES = MF_ROWS * ROW_BYTES;
-    static constexpr int NT = NWAVES * 64;
-    static constexpr int CPT = TILE_BYTES / (NT * 16);      // 16-byte glds per thread and tile
-    static constexpr int AUX = (METRIC == COSINE) ? 0 : (METRIC == EUCLIDEAN ? 2 : 1);  // 4-byte glds: |x|, |x|^2
-    static constexpr int LPT = CPT + AUX;                   // VM operations per wave and tile
-    static constexpr int RING = (MODE == 1) ? 1024 : 0;
-    static constexpr int SEG = RING / NWAVES > 0 ? RING / NWAVES : 1;
-    static constexpr int RING_BYTES = RING * 10 + 64;
-    static constexpr int AUX_BYTES = 512;                   // per buffer: two 256-byte dword-glds images
-    static constexpr int NB_FIT = (160 * 1024 - RING_BYTES) / (TILE_BYTES + AUX_BYTES);
-    static constexpr int NB = NB_FIT > 5 ? 5 : NB_FIT;
-    static constexpr int D = NB - 2;                        // tiles in flight beyond the one being waited for
-    static constexpr int LDS_BYTES = NB * (TILE_BYTES + AUX_BYTES) + RING_BYTES;
-    static_assert(TILE_BYTES % (NT * 16) == 0, "a tile is a whole number of glds per thread");
-    static_assert(NB >= 3, "three LDS buffers are the minimum for the mid-tile barrier");
-    static_assert(CPR % 16 == 0, "the XOR swizzle stays inside 16-chunk blocks");
-};
-
-extern __shared__ __attribute__((aligned(1024))) unsigned char vl_dyn_lds[];
-
-template <int N>
-__device__ __forceinline__ void wait_vm()
-{
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-template <int KSTEPS, int MODE, int METRIC, int NWAVES, int QT>
-__global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan_dma(const __bf16* __restrict__ slab16,
-                                                       const float* __restrict__ row_nrm,
-                                                       const float* __restrict__ row_sqn,
-                                                       const __bf16* __restrict__ q16, uint32_t nq, uint32_t n_tiles,
-                                                       uint32_t n_rows, int* __restrict__ gmax, uint32_t n_groups,
-                                                       const float* __restrict__ thr, Cand32* __restrict__ cand,
-                                                       uint32_t* __restrict__ cnt, uint32_t cap, uint32_t tile_begin)
-{
-    using C = DmaCfg<KSTEPS, MODE, METRIC, NWAVES>;
-    constexpr int LDB = KSTEPS * 16;
-    constexpr int CPR = C::CPR, ROW_BYTES = C::ROW_BYTES, TILE_BYTES = C::TILE_BYTES, NT = C::NT, CPT = C::CPT;
-    constexpr int NB = C::NB, D = C::D, LPT = C::LPT, RING = C::RING, SEG = C::SEG;
-    constexpr int MF_QPB = NWAVES * 32 * QT;
-    // all LDS is ONE array: a second __shared__ object beside a glds staging array can make hipcc wait
-    // vmcnt(0) before every fragment read
-    unsigned char* const tiles = vl_dyn_lds;                                                  // [NB][TILE_BYTES]
-    float* const aux_nrm = reinterpret_cast<float*>(vl_dyn_lds + NB * TILE_BYTES);            // [NB][64]
-    float* const aux_sqn = aux_nrm + NB * 64;                                                 // [NB][64]
-    float* const ring_key = reinterpret_cast<float*>(vl_dyn_lds + NB * (TILE_BYTES + C::AUX_BYTES));
-    uint32_t* const ring_pos = reinterpret_cast<uint32_t*>(ring_key + RING);
-    unsigned short* const ring_q = reinterpret_cast<unsigned short*>(ring_pos + RING);
-    uint32_t* const wave_cnt = reinterpret_cast<uint32_t*>(ring_q + RING);
-    uint32_t my_cnt = 0;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int col = lane & 31, half = lane >> 5;
-    uint32_t q[QT];
-    bool q_valid[QT];
-    bf16x8 bfrag[QT][KSTEPS];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        q[qt] = blockIdx.y * MF_QPB + (wave * QT + qt) * 32 + col;
-        q_valid[qt] = q[qt] < nq;
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s)
-            bfrag[qt][s] = *reinterpret_cast<const bf16x8*>(q16 + (size_t)q[qt] * LDB + 16 * s + 8 * half);
-    }
-    float thr_q[QT], run_max[QT];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        thr_q[qt] = INFINITY;
-        if (MODE == 1 && q_valid[qt]) thr_q[qt] = thr[q[qt]];
-        run_max[qt] = -INFINITY;
-    }
-    // Every ordinary load above must be complete -- and known to hipcc to be complete -- before the first
-    // glds: beside a glds in flight hipcc waits vmcnt(0) at the first use of any VGPR-destination load it
-    // still believes pending, which here would be the first MFMA of EVERY tile.  An empty asm that
-    // "uses" the registers makes the compiler place that wait here, once.
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) asm volatile("" : "+v"(bfrag[qt][s]));
-        asm volatile("" : "+v"(thr_q[qt]));
-    }
-
-    const uint32_t t0 = tile_begin + blockIdx.x, t_end = n_tiles, t_step = gridDim.x;
-    if (t0 >= t_end) {
-        if (MODE == 0) {
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
-                if (q_valid[qt] && half == 0 && blockIdx.x < n_groups)
-                    gmax[(size_t)q[qt] * n_groups + blockIdx.x] = enc_f(-INFINITY);
-        }
-        return;
-    }
-    const uint32_t n_my = (t_end - 1 - t0) / t_step + 1;
-    const uint32_t t_last = t0 + (n_my - 1) * t_step;
-
-    // glds sources: image chunk p = (wave * CPT + i) * 64 + lane holds chunk (p % CPR) ^ (row & 15) of row p / CPR
-    uint32_t src_row[CPT], src_off[CPT];
-#pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-        const uint32_t p = (uint32_t)((wave * CPT + i) * 64 + lane);
-        const uint32_t r = p / CPR, cc = p % CPR;
-        src_row[i] = r;
-        src_off[i] = (cc ^ (r & 15u)) * 16u;
-    }
-    const unsigned char* const slab_b = reinterpret_cast<const unsigned char*>(slab16);
-    auto issue_tile = [&](uint32_t seq, uint32_t b) {  // seq-th tile of this workgroup -> buffer b (clamped at the tail)
-        const uint32_t tile = seq < n_my ? t0 + seq * t_step : t_last;
-        const uint32_t row0 = tile * MF_ROWS;
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            uint32_t row = row0 + src_row[i];
-            row = row < n_rows ? row : n_rows - 1;  // rows past the end are masked in the epilogue
-            const unsigned char* src = slab_b + (size_t)row * ROW_BYTES + src_off[i];
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(tiles + b * TILE_BYTES +
-                                                                                       (wave * CPT + i) * 1024),
-                                             16, 0, 0);
-        }
-        if (METRIC != COSINE) {  // every wave fetches the same 32 scalars to the same place (uniform VM count per wave)
-            uint32_t arow = row0 + (uint32_t)col;
-            arow = arow < n_rows ? arow : n_rows - 1;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row_nrm + arow),
-                                             (__attribute__((address_space(3))) void*)(aux_nrm + b * 64), 4, 0, 0);
-            if (METRIC == EUCLIDEAN)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row_sqn + arow),
-                                                 (__attribute__((address_space(3))) void*)(aux_sqn + b * 64), 4, 0, 0);
-        }
-    };
-    // fragment addresses: row `col`, logical chunk 2 s + half sits at ((2 s + half) ^ (col & 15)) inside its 16-chunk block
-    uint32_t frag_off[8];
-#pragma unroll
-    for (int t8 = 0; t8 < 8; ++t8)
-        frag_off[t8] = (uint32_t)col * ROW_BYTES + (((uint32_t)(2 * t8 + half) ^ ((uint32_t)col & 15u)) << 4);
-    auto read_frag = [&](uint32_t b, int s) -> bf16x8 {
-        return *reinterpret_cast<const bf16x8*>(tiles + b * TILE_BYTES + frag_off[s & 7] + (s >> 3) * 256);
-    };
-
-    auto flush_ring = [&]() {  // caller has published wave_cnt[] and passed a barrier
-        bool overflow = false;
-#pragma unroll
-        for (int w = 0; w < NWAVES; ++w) overflow = overflow || wave_cnt[w] > (uint32_t)SEG;
-        for (uint32_t e = tid; e < (uint32_t)(NWAVES * SEG); e += NT) {
-            const uint32_t w = e / SEG, i = e % SEG;
-            if (i < wave_cnt[w]) {
-                const uint32_t qq = blockIdx.y * MF_QPB + ring_q[e];
-                const uint32_t slot = atomicAdd(&cnt[qq], 1u);
-                if (slot < cap) {
-                    Cand32 c;
-                    c.key = ring_key[e];
-                    c.pos = ring_pos[e];
-                    cand[(size_t)qq * cap + slot] = c;
-                }
-            }
-        }
-        if (overflow && tid < MF_QPB) {
-            const uint32_t qq = blockIdx.y * MF_QPB + tid;
-            if (qq < nq) atomicAdd(&cnt[qq], cap + 1u);
-        }
-        my_cnt = 0;
-        lds_barrier();
-    };
-
-    // Epilogue of one finished tile, cut into five steps that the main loop issues BETWEEN the MFMA groups
-    // of the next tile (each step is a handful of VALU operations that execute in the shadow of the MFMAs
-    // just issued; as one block after the tile they cost 19 % of the kernel):
-    //   steps 0..3: the four keys of register group g4 -> their maximum m4[qt][g4];
-    //   step 4:     m = max(m4), MODE 0: running maximum; MODE 1: compare with T_q and, rarely, the hit path
-    //               (which recomputes the keys it needs from the accumulators).
-    auto key_of = [&](const f32x16& a, int reg, const f32x4& nr, const f32x4& sq) -> float {
-        float key = a[reg];                                                  // cosine: x^.q
-        if (METRIC == DOT) key *= nr[reg & 3];                               // x.q
-        if (METRIC == EUCLIDEAN) key = 2.0f * key * nr[reg & 3] - sq[reg & 3];  // |q|^2 - |x - q|^2
-        return key;
-    };
-    auto masked = [&](float key, int reg, uint32_t row0, bool live) -> float {
-        return (!live || row0 + (uint32_t)((reg & 3) + 8 * (reg >> 2) + 4 * half) >= n_rows) ? -INFINITY : key;
-    };
-    float m4[QT][4];
-    auto epi_slice = [&](const f32x16(&acc)[QT], int g4, uint32_t tile, bool live, uint32_t b) {
-        const uint32_t row0 = tile * MF_ROWS;
-        const bool partial = row0 + MF_ROWS > n_rows || !live;  // wave-uniform
-        f32x4 nr = {1.f, 1.f, 1.f, 1.f}, sq = {0.f, 0.f, 0.f, 0.f};
-        if (METRIC != COSINE) nr = *reinterpret_cast<const f32x4*>(aux_nrm + b * 64 + 8 * g4 + 4 * half);
-        if (METRIC == EUCLIDEAN) sq = *reinterpret_cast<const f32x4*>(aux_sqn + b * 64 + 8 * g4 + 4 * half);
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            float k4[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                k4[jj] = key_of(acc[qt], 4 * g4 + jj, nr, sq);
-                if (partial) k4[jj] = masked(k4[jj], 4 * g4 + jj, row0, live);
-            }
-            m4[qt][g4] = fmaxf(fmaxf(k4[0], k4[1]), fmaxf(k4[2], k4[3]));
-        }
-    };
-    auto epi_final = [&](const f32x16(&acc)[QT], uint32_t tile, bool live, uint32_t b) {
-        const uint32_t row0 = tile * MF_ROWS;
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const float m = fmaxf(fmaxf(m4[qt][0], m4[qt][1]), fmaxf(m4[qt][2], m4[qt][3]));
-            if (MODE == 0) {
-                run_max[qt] = fmaxf(run_max[qt], m);
-            } else if (__builtin_amdgcn_ballot_w64(m >= thr_q[qt]) != 0ull) {
-                // Rare per wave-tile, but the whole workgroup waits for the slowest wave at the next barrier:
-                // no atomic (the wave appends to its own ring segment), register groups without a candidate
-                // are skipped with one ballot, slots come from ballot + mbcnt.
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    if (__builtin_amdgcn_ballot_w64(m4[qt][g4] >= thr_q[qt]) == 0ull) continue;  // wave-uniform
-                    f32x4 nr = {1.f, 1.f, 1.f, 1.f}, sq = {0.f, 0.f, 0.f, 0.f};
-                    if (METRIC != COSINE) nr = *reinterpret_cast<const f32x4*>(aux_nrm + b * 64 + 8 * g4 + 4 * half);
-                    if (METRIC == EUCLIDEAN) sq = *reinterpret_cast<const f32x4*>(aux_sqn + b * 64 + 8 * g4 + 4 * half);
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const int reg = 4 * g4 + jj;
-                        const float key = masked(key_of(acc[qt], reg, nr, sq), reg, row0, live);
-                        const bool is_cand = key >= thr_q[qt] && key > -INFINITY;  // masked rows are -inf; T_q may be too
-                        const unsigned long long mk = __builtin_amdgcn_ballot_w64(is_cand);
-                        if (mk != 0ull) {
-                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32),
-                                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                            const uint32_t slot = my_cnt + rank;
-                            if (is_cand && slot < (uint32_t)SEG) {
-                                const uint32_t e = (uint32_t)wave * SEG + slot;
-                                ring_key[e] = key;
-                                ring_pos[e] = row0 + (uint32_t)((reg & 3) + 8 * (reg >> 2) + 4 * half);
-                                ring_q[e] = (unsigned short)((wave * QT + qt) * 32 + col);
-                            }
-                            my_cnt += (uint32_t)__popcll(mk);
-                        }
-                    }
-                }
-            }
-        }
-    };
-
-    constexpr int GS = 4;
-    constexpr int NG = KSTEPS / GS;
-    constexpr int MID = NG / 2 - 1;
-    static_assert(KSTEPS % GS == 0 && (NG % 2) == 0, "an even number of K groups");
-
-    // prologue: tiles 0..D are issued, tile 0 is waited for and published
-#pragma unroll
-    for (int j = 0; j <= D; ++j) issue_tile((uint32_t)j, (uint32_t)j);
-    wait_vm<D * LPT>();
-    lds_barrier();
-    bf16x8 afrag[2][GS];
-#pragma unroll
-    for (int jj = 0; jj < GS; ++jj) afrag[0][jj] = read_frag(0, jj);
-
-    f32x16 acc_prev[QT];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc_prev[qt][r] = 0.0f;
-    uint32_t b_cur = 0, b_prev = 0, tile_prev = t0;
-    bool live_prev = false;
-
-    for (uint32_t i = 0; i < n_my; ++i) {
-        const uint32_t tile = t0 + i * t_step;
-        const uint32_t b_next = b_cur + 1 == NB ? 0 : b_cur + 1;
-        f32x16 acc[QT];
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[qt][r] = 0.0f;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-#pragma unroll
-            for (int jj = 0; jj < GS; ++jj)  // fragments one group ahead; the last group fetches tile i+1's first
-                afrag[(g + 1) & 1][jj] = (g + 1 < NG) ? read_frag(b_cur, (g + 1) * GS + jj) : read_frag(b_next, jj);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int jj = 0; jj < GS; ++jj)
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt)
-                    acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[g & 1][jj], bfrag[qt][g * GS + jj], acc[qt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            // The previous tile's epilogue, spread over the MFMA groups: step e goes behind group e * SPAN / 5.
-            // Dot / Euclidean read the previous tile's row norms from its LDS buffer, which the middle block
-            // below hands to a new tile: their steps all sit at or before group MID.
-            constexpr int SPAN = (METRIC == COSINE) ? NG : MID + 1;
-#pragma unroll
-            for (int e = 0; e < 5; ++e) {
-                if (e * SPAN / 5 == g) {
-                    if (e < 4) epi_slice(acc_prev, e, tile_prev, live_prev, b_prev);
-                    else epi_final(acc_prev, tile_prev, live_prev, b_prev);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            if (g == MID) {
-                // tile i+1: my share has landed (D-1 younger tiles may still fly) -> barrier: everyone's has, and
-                // everyone is done with tile i-1, whose buffer takes tile i+D+1
-                wait_vm<(D - 1) * LPT>();
-                lds_barrier();
-                issue_tile(i + 1 + D, b_cur == 0 ? (uint32_t)(NB - 1) : b_cur - 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) acc_prev[qt] = acc[qt];
-        tile_prev = tile;
-        live_prev = true;
-        b_prev = b_cur;
-        b_cur = b_next;
-        if (MODE == 1 && (i & 15u) == 15u) {  // every 16 tiles: flush when some wave's ring segment is half full
-            if (lane == 0) wave_cnt[wave] = my_cnt;
-            lds_barrier();
-            uint32_t fullest = 0;
-#pragma unroll
-            for (int w = 0; w < NWAVES; ++w) fullest = wave_cnt[w] > fullest ? wave_cnt[w] : fullest;
-            if (fullest >= (uint32_t)(SEG / 2)) flush_ring();
-            else lds_barrier();
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) epi_slice(acc_prev, e, tile_prev, live_prev, b_prev);
-    epi_final(acc_prev, tile_prev, live_prev, b_prev);
-    wait_vm<0>();  // the clamped tail tiles are still landing: nothing may be in flight when the LDS is released
-    if (MODE == 1) {
-        if (lane == 0) wave_cnt[wave] = my_cnt;
-        lds_barrier();
-        flush_ring();
-    }
-    if (MODE == 0) {
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const float other = __shfl_xor(run_max[qt], 32);
-            const float mx = fmaxf(run_max[qt], other);
-            if (q_valid[qt] && half == 0 && blockIdx.x < n_groups) gmax[(size_t)q[qt] * n_groups + blockIdx.x] = enc_f(mx);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Single-query scan of the bf16 slab (opt-in candidate filter: half the HBM bytes of the f32 scan).
 // Same structure as k_scan (kernels.hip): G lanes share a row, 16-byte non-temporal loads straight to
 // registers (8 bf16 each), shuffle reduction, one sorted top-64 list per wave.  The query stays f32
@@ -1010,36 +645,17 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
         }
     }
 
-    // tile staging: LDS-DMA kernel (default) or the register-staged one (VL_MFMA_IMPL=reg)
-    const char* impl = getenv("VL_MFMA_IMPL");
-    const bool use_dma = !(impl && impl[0] == 'r');
     bool launched = false;
 #define VL_LAUNCH3(K, MET, NW, QTT)                                                                                     \
     {                                                                                                                   \
-        auto k0 = use_dma ? k_mfma_scan_dma<K, 0, MET, NW, QTT> : k_mfma_scan<K, 0, MET, NW, QTT>;                      \
-        auto k1 = use_dma ? k_mfma_scan_dma<K, 1, MET, NW, QTT> : k_mfma_scan<K, 1, MET, NW, QTT>;                      \
-        const size_t lds0 = use_dma ? (size_t)DmaCfg<K, 0, MET, NW>::LDS_BYTES : 0;                                     \
-        const size_t lds1 = use_dma ? (size_t)DmaCfg<K, 1, MET, NW>::LDS_BYTES : 0;                                     \
-        if (use_dma) {                                                                                                  \
-            static bool attr_done = false; /* per instantiation: raise the dynamic LDS limit above 64 KB once */       \
-            if (!attr_done) {                                                                                           \
-                hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k0),                                  \
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);             \
-                if (ea == hipSuccess)                                                                                   \
-                    ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k1),                                         \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);                    \
-                if (ea != hipSuccess) return ea;                                                                        \
-                attr_done = true;                                                                                       \
-            }                                                                                                           \
-        }                                                                                                               \
-        hipLaunchKernelGGL(k0, grid0, dim3(NW * 64), lds0, s, slab, row_norm, row_sqnorm, q16, nq,                     \
+        hipLaunchKernelGGL((k_mfma_scan<K, 0, MET, NW, QTT>), grid0, dim3(NW * 64), 0, s, slab, row_norm, row_sqnorm, q16, nq,       \
                            sample_tiles, (uint32_t)sample_rows, w.gmax, n_groups, (const float*)nullptr,               \
                            (Cand32*)nullptr, (uint32_t*)nullptr, 0u, 0u);                                               \
         hipLaunchKernelGGL(k_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.gmax, n_groups, nq, w.thr);             \
         for (int st = 0; st < n_stages; ++st) {                                                                         \
             const uint32_t tb = stage_end[st], te = stage_end[st + 1];                                                  \
             const dim3 grid1((uint32_t)std::min<uint32_t>(te - tb, (uint32_t)pass1_blocks), nq_pad / qpb);              \
-            hipLaunchKernelGGL(k1, grid1, dim3(NW * 64), lds1, s, slab, row_norm, row_sqnorm, q16, nq,                  \
+            hipLaunchKernelGGL((k_mfma_scan<K, 1, MET, NW, QTT>), grid1, dim3(NW * 64), 0, s, slab, row_norm, row_sqnorm, q16, nq,   \
                                te, (uint32_t)n_rows, (int*)nullptr, 0u, w.thr, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, tb); \
             if (st + 1 < n_stages)                                                                                      \
                 hipLaunchKernelGGL(k_refine_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.cand, w.cnt,             \
