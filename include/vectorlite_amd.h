@@ -227,6 +227,10 @@ int vl_index_set_single_filter(vl_index *h, int mode);
 int vl_index_set_coalescing(vl_index *h, int max_batch, int window_us);
 int vl_index_coalesce_stats(const vl_index *h, uint64_t *batches, uint64_t *queries);
 
+/* HNSW handle: queries walked and Metric::distance evaluations (src/index/hnsw.rs:113-174) made for them since
+ * creation.  Bytes touched per query = evaluations x dim x 8 (the walk reads the f64 master rows). */
+int vl_index_hnsw_walk_stats(const vl_index *h, uint64_t *queries, uint64_t *distance_evals);
+
 /* Kernel timing with HIP events on the stream the scan kernel runs on.
  * enable != 0 starts accumulating; vl_index_profile_read returns and clears the totals. */
 int vl_index_profile_enable(vl_index *h, int enable);

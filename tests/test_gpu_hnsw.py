@@ -194,3 +194,18 @@ def test_clone_and_export_keep_graph_and_tombstones(V):
     assert idx.get_vector(int(ids[5])) is not None and c.get_vector(int(ids[5])) is None
     with pytest.raises(V.IndexOpError):
         c.delete(int(ids[17]))  # the tombstone came along: "does not exist"
+
+
+def test_walk_stats_count_distance_evaluations(V):
+    rng = np.random.default_rng(3)
+    n, dim = 3000, 16
+    z = rng.standard_normal((n, dim))
+    idx = V.HNSWIndex(dim, V.SimilarityMetric.Euclidean)
+    idx.add_rows(np.arange(n, dtype=np.uint64), z)
+    assert idx.walk_stats() == (0, 0)
+    idx.search_batch(z[:50] + 0.01, 10, V.SimilarityMetric.Euclidean, ef=32)
+    q, e = idx.walk_stats()
+    assert q == 50 and 50 * 32 <= e <= 50 * n  # at least the beam is evaluated, never more than every node once
+    idx.search(z[7], 5, V.SimilarityMetric.Euclidean)
+    q2, e2 = idx.walk_stats()
+    assert q2 == 51 and e2 > e

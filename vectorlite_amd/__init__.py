@@ -397,6 +397,12 @@ class HNSWIndex:
                 pass
             self._h = None
 
+    def walk_stats(self) -> Tuple[int, int]:
+        """(queries walked, distance evaluations made for them) since creation."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _raise(self._L.vl_index_hnsw_walk_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def clone(self) -> "HNSWIndex":
         """Deep copy (rows + device graph, tombstones included): #[derive(Clone)] on HNSWIndex."""
         h = C.c_void_p()

@@ -402,6 +402,13 @@ int vl_index_coalesce_stats(const vl_index* h, uint64_t* batches, uint64_t* quer
     return VL_OK;
 }
 
+int vl_index_hnsw_walk_stats(const vl_index* h, uint64_t* queries, uint64_t* distance_evals)
+{
+    if (!h || !h->hnsw) return VL_ERR_INVALID_ARG;
+    h->hnsw->walk_stats(queries, distance_evals);
+    return VL_OK;
+}
+
 int vl_index_profile_enable(vl_index* h, int enable)
 {
     if (!h || !h->flat) return VL_ERR_INVALID_ARG;

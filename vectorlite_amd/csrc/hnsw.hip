@@ -168,7 +168,7 @@ __device__ __forceinline__ LayerView layer_of(const HnswGraphView& g, uint32_t n
 // their stamps are set.
 template <int METRIC, int S>
 __device__ __forceinline__ void beam_layer(const HnswGraphView& g, const double* q, int layer, uint32_t* stamps,
-                                           uint32_t epoch, BeamList<S>& L, int ef)
+                                           uint32_t epoch, BeamList<S>& L, int ef, uint32_t* evals = nullptr)
 {
     const int lane = lane_id();
     for (;;) {
@@ -187,6 +187,7 @@ __device__ __forceinline__ void beam_layer(const HnswGraphView& g, const double*
         }
         unsigned long long de = ~0ull;
         if (act) de = row_distance<METRIC>(g.master + (size_t)e * g.dim, q, g.dim);
+        if (evals) *evals += (uint32_t)__popcll(__ballot(act));  // wave-uniform count of rows walked
         // the current worst only shrinks while we insert: a stale value lets a few extra lanes through,
         // insert() re-checks the rank
         unsigned long long w;
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(256) void k_hnsw_search(HnswGraphView g, const doub
         BeamList<S> L;
         L.init();
         epoch += 1;
+        uint32_t evals = 1;  // the entry point
         {
             unsigned long long d0 = 0;
             if (lane == 0) d0 = row_distance<METRIC>(g.master + (size_t)entry * g.dim, q, g.dim);
@@ -240,10 +242,10 @@ __global__ __launch_bounds__(256) void k_hnsw_search(HnswGraphView g, const doub
             if (lane == 0) stamps[entry] = epoch;
         }
         for (int layer = max_level; layer >= 1; --layer) {
-            beam_layer<METRIC, S>(g, q, layer, stamps, epoch, L, 1);
+            beam_layer<METRIC, S>(g, q, layer, stamps, epoch, L, 1, &evals);
             next_layer(L, stamps, epoch);
         }
-        beam_layer<METRIC, S>(g, q, 0, stamps, epoch, L, (int)ef);
+        beam_layer<METRIC, S>(g, q, 0, stamps, epoch, L, (int)ef, &evals);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const uint32_t j = s * 64 + lane;
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256) void k_hnsw_search(HnswGraphView g, const doub
                 HnswHit h;
                 h.dist = walk_key_to_u64(L.d[s]);  // the reference's u64 distance
                 h.node = L.v[s] == HNSW_NONE ? HNSW_NONE : (L.v[s] & ~EXPANDED);
-                h.pad = 0;
+                h.evals = j == 0 ? evals : 0u;
                 out[(size_t)qi * ef + j] = h;
             }
         }

@@ -43,7 +43,7 @@ struct HnswGraphView {
 struct HnswHit {  // one neighbour returned by a walk
     unsigned long long dist;  // Metric::distance(query, node) as the reference defines it
     uint32_t node;
-    uint32_t pad;
+    uint32_t evals;  // entry 0 of a query: distance evaluations of the whole walk; else 0
 };
 
 // Query-time walk: nq queries (f64 [nq, dim]) -> out[nq][ef] sorted by (dist asc, node asc),

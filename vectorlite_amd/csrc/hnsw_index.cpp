@@ -317,6 +317,12 @@ int HnswIndex::get_vector(uint64_t id, double* out) const
     return OK;
 }
 
+void HnswIndex::walk_stats(uint64_t* queries, uint64_t* distance_evals) const
+{
+    if (queries) *queries = stat_queries_.load();
+    if (distance_evals) *distance_evals = stat_evals_.load();
+}
+
 int HnswIndex::clone(HnswIndex** out) const
 {
     if (!out) return ERR_INVALID_ARG;
@@ -472,9 +478,11 @@ int HnswIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_len, 
         double score;
     };
     std::vector<Res> res;
+    stat_queries_.fetch_add(nq, std::memory_order_relaxed);
     for (uint64_t qi = 0; qi < nq; ++qi) {
         res.clear();
         const HnswHit* hits = h_hits_ + qi * ef_walk;
+        stat_evals_.fetch_add(hits[0].evals, std::memory_order_relaxed);
         // `neighbors` holds max_candidates slots (:442-448): the walk's closest max_candidates
         for (uint64_t i = 0; i < ef_walk && res.size() < max_candidates; ++i) {
             const HnswHit& h = hits[i];

@@ -4,6 +4,7 @@
 // tombstones exactly like the reference, src/index/hnsw.rs:400-414).
 #pragma once
 
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
@@ -46,6 +47,9 @@ public:
     uint64_t graph_nodes() const { return n_nodes_; }
     // #[derive(Clone)] on HNSWIndex (persistence clones the wrapper, src/persistence.rs:118): a deep copy of
     // the rows and of the device graph, tombstones included.
+    // queries walked and Metric::distance evaluations made by them since creation (SURVEY 8(d) C4:
+    // bytes touched per query = evaluations x dim x 8, the f64 master rows the walk reads)
+    void walk_stats(uint64_t* queries, uint64_t* distance_evals) const;
     int clone(HnswIndex** out) const;
     // live rows in node (insertion) order: the `vector_values` member of the serialised form
     int export_rows(uint64_t* out_ids, double* out_values) const;
@@ -91,6 +95,8 @@ private:
     std::vector<uint64_t> node_id_;
     std::vector<uint8_t> live_;
     uint64_t live_count_ = 0;
+
+    mutable std::atomic<uint64_t> stat_queries_{0}, stat_evals_{0};
 
     // search scratch
     mutable double* d_q_ = nullptr;
