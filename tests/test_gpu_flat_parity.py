@@ -376,7 +376,7 @@ def test_batch_scan_kernel_parity(V, O, dim):
                 assert [int(ids[p]) for p in pos[i]] == ri.tolist()
 
 
-@pytest.mark.parametrize("dim,n", [(128, 9000), (384, 5000), (768, 3000), (100, 4000), (384, 1500)])
+@pytest.mark.parametrize("dim,n", [(128, 9000), (384, 12000), (768, 8500), (100, 4000), (384, 1500), (128, 8191), (128, 100000), (100, 9000)])
 def test_mfma_large_batch_parity(V, O, dim, n):
     """>= 64 queries per call take the bf16 MFMA candidate filter (cosine, dot); results must still be
     the oracle's bit for bit, including queries the filter cannot certify (ties, out-of-domain)."""
@@ -393,9 +393,20 @@ def test_mfma_large_batch_parity(V, O, dim, n):
     Q[5] = Q[5] * 1e100
     Q[9] = 0.0
     Q[11] = rows[500] * 0.999 + Q[11] * 0.001
+    # which pipeline answers: one bf16 MFMA pass for the whole batch once the index has MFMA_MIN_ROWS = 8192
+    # rows (below that the sampling pass cannot produce thresholds), else 19 f32 passes of 8 queries
+    gpu.profile_read()
+    gpu.profile_enable(True)
+    gpu.search_batch(Q, 10, 0)
+    gpu.profile_enable(False)
+    passes = gpu.profile_read()[0]
+    if n >= 8192 and dim != 100:  # dim 100 pads to 112 bf16 columns: no MFMA shape
+        assert passes <= 1 + 24, passes  # the MFMA pass + the few queries it cannot certify (ties, out-of-domain), one by one
+    else:
+        assert passes == 19 if dim != 100 else nq - 2 <= passes <= nq, passes  # dim 100 has no 8-query f32 shape: one by one (the out-of-domain query skips the scan)
     for name in ("cosine", "dotproduct", "euclidean"):
         m = M[name]
-        for k in (1, 10, 32, 48):
+        for k in (1, 10, 48):
             bi, bs, bn = gpu.search_batch(Q, k, m)
             for i in range(nq):
                 ri, rs = ref.search(Q[i], k, m)
@@ -680,3 +691,50 @@ def test_bf16_single_query_filter_is_exact(V, O, dim):
     gpu.add(V.Vector(10 ** 12, rows[3] * 1.0000001))
     ref.add(10 ** 12, rows[3] * 1.0000001)
     assert_same(V, gpu.search_arrays(rows[3], 5, 0), ref.search(rows[3], 5, 0), "after add")
+
+
+def test_seeded_fuzz_adversarial_values(V, O):
+    """240 seeded cases with random shapes and unfriendly values: mixed magnitudes up to the domain
+    edge (2^40, 2^-40), denormals, signed zeros, integer grids (exact ties in every metric), repeated
+    rows, zero rows, and queries drawn from the rows themselves.  Singles, and a batch per case."""
+    rng = np.random.default_rng(20251003)
+    kinds = ("gauss", "grid", "mixed_mag", "tiny", "huge", "dups")
+    for case in range(240):
+        kind = kinds[case % len(kinds)]
+        dim = int(rng.choice([1, 2, 3, 7, 8, 16, 31, 64, 100, 128, 200]))
+        n = int(rng.choice([1, 2, 5, 63, 64, 65, 130, 700]))
+        if kind == "gauss":
+            rows = rng.standard_normal((n, dim))
+        elif kind == "grid":
+            rows = rng.integers(-2, 3, size=(n, dim)).astype(np.float64)
+        elif kind == "mixed_mag":
+            rows = rng.standard_normal((n, dim)) * np.exp2(rng.integers(-30, 31, size=(n, 1)).astype(np.float64))
+        elif kind == "tiny":
+            rows = rng.standard_normal((n, dim)) * 2.0 ** -36
+            rows[rng.integers(0, n)] = 5e-324 * rng.integers(0, 3, size=dim)  # denormals (norm < 2^-40: out of the fast domain)
+        elif kind == "huge":
+            rows = rng.uniform(-1, 1, size=(n, dim)) * 2.0 ** 39
+        else:
+            base = rng.standard_normal((max(1, n // 4), dim))
+            rows = base[rng.integers(0, base.shape[0], size=n)]
+        if n > 3:
+            rows[rng.integers(0, n)] = 0.0
+            rows[rng.integers(0, n)] *= -0.0 if kind == "grid" else 1.0
+        ids = permuted_ids(n)
+        gpu = V.FlatIndex(dim)
+        gpu.add_rows(ids, rows, validate=False)
+        ref = O.FlatOracle(dim, ids, rows)
+        Q = [rows[rng.integers(0, n)].copy(), rng.standard_normal(dim) * (2.0 ** 20 if kind == "huge" else 1.0),
+             np.zeros(dim)]
+        if kind == "grid":
+            Q.append(rng.integers(-2, 3, size=dim).astype(np.float64))
+        for q in Q:
+            for m in range(4):
+                for k in (1, 10, n):
+                    assert_same(V, gpu.search_arrays(q, k, m), ref.search(q, k, m), (case, kind, dim, n, m, k))
+        Qb = np.stack(Q + [rows[i % n] * 0.5 for i in range(9 - len(Q))])
+        m = case % 4
+        bi, bs, bn = gpu.search_batch(Qb, 10, m)
+        for j in range(Qb.shape[0]):
+            want = ref.search(Qb[j], 10, m)
+            assert bi[j, : bn[j]].tolist() == want[0].tolist() and bs[j, : bn[j]].tolist() == want[1].tolist(), (case, kind, j)

@@ -621,8 +621,9 @@ int GpuFlatIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_le
     } rel{this, ws};
     hipStream_t st = ws->stream;
 
-    const bool batchable = nq > 1 && force_path_.load() == 0 && k_eff <= (uint64_t)KFAST_MAX &&
-                           n_out_of_domain_ == 0 && scan_batch_supported(ld_);
+    // row lengths without an 8-query f32 shape can still take the MFMA filter (its bf16 slab is padded to 128)
+    const bool f32_batch = scan_batch_supported(ld_);
+    const bool batchable = nq > 1 && force_path_.load() == 0 && k_eff <= (uint64_t)KFAST_MAX && n_out_of_domain_ == 0;
     auto out_at = [&](uint64_t* base, uint64_t qi) { return base ? base + qi * k : nullptr; };
     auto single = [&](uint64_t qi, bool skip_fast) -> int {
         return search_locked(ws, queries + qi * dim_, k_eff, metric, out_at(out_pos, qi), out_at(out_ids, qi),
@@ -639,7 +640,7 @@ int GpuFlatIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_le
     const bool mfma_on = !(mf_env && mf_env[0] == '0');
     const char* mf_min = getenv("VL_MFMA_MIN_BATCH");
     const uint64_t mfma_min = mf_min && *mf_min ? (uint64_t)atoi(mf_min) : (uint64_t)MFMA_MIN_BATCH;
-    if (mfma_on && nq >= mfma_min && mfma_scan_supported((uint32_t)dim_, metric)) {
+    if (mfma_on && nq >= mfma_min && n >= MFMA_MIN_ROWS && mfma_scan_supported((uint32_t)dim_, metric)) {
         VL_TRY(search_batch_mfma(ws, queries, nq, k, k_eff, metric, out_pos, out_ids, out_scores, out_n, &done));
         uint64_t left = 0;
         for (uint64_t qi = 0; qi < nq; ++qi) left += done[qi] ? 0 : 1;
@@ -647,11 +648,15 @@ int GpuFlatIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_le
             set_last_path(PATH_FAST);
             return OK;
         }
-        if (left < nq) {  // few stragglers: answer them one by one on the f32 path
+        if (left < nq || !f32_batch) {  // few stragglers: answer them one by one on the f32 path
             for (uint64_t qi = 0; qi < nq; ++qi)
                 if (!done[qi]) VL_TRY(single(qi, false));
             return OK;
         }
+    }
+    if (!f32_batch) {
+        for (uint64_t qi = 0; qi < nq; ++qi) VL_TRY(single(qi, false));
+        return OK;
     }
 
     const bool prof = profile_.load();

@@ -459,7 +459,11 @@ __global__ __launch_bounds__(1024) void k_merge_finalize(const Cand32* __restric
         const uint32_t k_eff = (uint64_t)k < n_rows ? k : (uint32_t)n_rows;
         uint32_t flags = 0;
         if (any_nan) flags |= RESULT_HAS_NAN | RESULT_NEEDS_EXACT;
-        if (n_rows > (uint64_t)KP) {
+        if (n_rows <= (uint64_t)KP) {
+            // the list must hold EVERY row; a shorter one (a candidate stage that overflowed or dropped rows)
+            // proves nothing
+            if ((uint64_t)n_cand < n_rows) flags |= RESULT_NEEDS_EXACT;
+        } else {
             // rows outside the candidate list exist: all of them have scan key <= the 64th key
             if (n_cand < KP) {
                 flags |= RESULT_NEEDS_EXACT;  // keys were not finite: outside the fast-path domain

@@ -621,8 +621,13 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     if (e != hipSuccess) return e;
 
     // pass 0: a sample of the tiles, one contiguous range per workgroup = one "group" per workgroup
+    // The threshold is exceeded by about 64 rows of the sample, i.e. by a fraction 64 / sample_rows of all
+    // rows: a wave then appends 32 queries x 512 rows x that fraction candidates per trip to its 128-entry
+    // ring segment.  A sample of at least 65536 rows (or the whole index) keeps that near 16; with only
+    // 8192 sampled rows an index of 10^5 rows overflowed the rings and every query fell back.
     uint32_t sample_tiles = n_tiles / 16;
-    if (sample_tiles < (uint32_t)MFMA_GROUPS) sample_tiles = n_tiles < (uint32_t)MFMA_GROUPS ? n_tiles : (uint32_t)MFMA_GROUPS;
+    const uint32_t min_sample = n_tiles < 2048u ? n_tiles : 2048u;
+    if (sample_tiles < min_sample) sample_tiles = min_sample;
     const uint32_t n_groups = sample_tiles < (uint32_t)MFMA_GROUPS ? sample_tiles : (uint32_t)MFMA_GROUPS;
     const dim3 grid0(n_groups, nq_pad / qpb);
     const uint64_t sample_rows = std::min<uint64_t>((uint64_t)sample_tiles * MF_ROWS, n_rows);

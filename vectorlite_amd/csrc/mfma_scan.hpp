@@ -13,6 +13,9 @@ namespace vl {
 constexpr int MFMA_GROUPS = 256;       // workgroups (= row groups) of the sampling pass
 constexpr int MFMA_CAND_CAP = 4096;    // candidate buffer entries per query
 constexpr int MFMA_MAX_BATCH = 1024;   // queries per launch sequence (scratch is sized for this)
+// Fewer rows than this (MFMA_GROUPS tiles of 32) leave the sampling pass with fewer than 64 groups: no
+// threshold, every score a candidate, guaranteed buffer overflow -- such indexes take the f32 batch path.
+constexpr uint64_t MFMA_MIN_ROWS = (uint64_t)MFMA_GROUPS * 32;
 constexpr int MFMA_MIN_BATCH = 8;      // below this the f32 batch path is used (measured: one bf16 pass of
                                        // 1.9 ms answers 8..256 queries; the f32 path needs 2.7 ms per 8)
 
