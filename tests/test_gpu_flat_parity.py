@@ -738,3 +738,58 @@ def test_seeded_fuzz_adversarial_values(V, O):
         for j in range(Qb.shape[0]):
             want = ref.search(Qb[j], 10, m)
             assert bi[j, : bn[j]].tolist() == want[0].tolist() and bs[j, : bn[j]].tolist() == want[1].tolist(), (case, kind, j)
+
+
+def test_stateful_fuzz_large_index_all_filters(V, O):
+    """An index big enough for every candidate filter (f32 scan, bf16 single-query filter, bf16 MFMA batch
+    filter) under a random stream of adds, bulk adds, deletes (present, absent, duplicated ids), failed adds
+    and clones; every search is compared with the oracle that received the same stream."""
+    rng = np.random.default_rng(424242)
+    dim, n0 = 128, 9000
+    rows = unit_rows(rng, n0, dim)
+    ids = permuted_ids(n0)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    live = ids.tolist()
+    next_id = 10 ** 12
+    for step in range(80):
+        op = rng.integers(0, 8)
+        if op == 0:  # single add
+            v = unit_rows(rng, 1, dim)[0] * float(rng.choice([1.0, 3.0, 0.25]))
+            gpu.add(V.Vector(next_id, v)); ref.add(next_id, v); live.append(next_id); next_id += 1
+        elif op == 1:  # bulk add
+            c = int(rng.integers(1, 60))
+            vs = unit_rows(rng, c, dim)
+            new = np.arange(next_id, next_id + c, dtype=np.uint64)
+            gpu.add_rows(new, vs)
+            for i in range(c):
+                ref.add(int(new[i]), vs[i])
+            live += new.tolist(); next_id += c
+        elif op == 2 and live:  # delete a live id
+            victim = live.pop(int(rng.integers(len(live))))
+            gpu.delete(victim); ref.delete(victim)
+        elif op == 3:  # delete an absent id: Ok, nothing happens (src/index/flat.rs:93-96)
+            gpu.delete(7); ref.delete(7)
+        elif op == 4 and live:  # duplicate id: refused, index unchanged
+            with pytest.raises(V.IndexOpError, match="already exists"):
+                gpu.add(V.Vector(live[0], unit_rows(rng, 1, dim)[0]))
+            with pytest.raises(O.OracleError):
+                ref.add(live[0], unit_rows(rng, 1, dim)[0])
+        elif op == 5:  # wrong dimension: refused
+            with pytest.raises(V.IndexOpError, match="dimension mismatch"):
+                gpu.add(V.Vector(next_id + 10 ** 6, np.ones(dim + 1)))
+        elif op == 6:  # the clone takes over (src/persistence.rs:118 clones the index)
+            gpu = gpu.clone()
+        else:
+            gpu.set_single_filter("bf16" if rng.random() < 0.5 else "f32")
+        assert len(gpu) == len(ref) == len(live)
+        m = int(rng.integers(0, 4))
+        k = int(rng.choice([1, 10, 48, 70]))
+        Q = unit_rows(rng, 12, dim)
+        Q[0] = np.asarray(gpu.get_vector(live[int(rng.integers(len(live)))]).values)  # an exact hit
+        assert_same(V, gpu.search_arrays(Q[0], k, m), ref.search(Q[0], k, m), (step, "single", m, k))
+        bi, bs, bn = gpu.search_batch(Q, k, m)
+        for j in range(12):
+            want = ref.search(Q[j], k, m)
+            assert bi[j, : bn[j]].tolist() == want[0].tolist() and bs[j, : bn[j]].tolist() == want[1].tolist(), (step, j, m, k)
