@@ -84,8 +84,9 @@ int vl_flat_from_rows(uint64_t dim, const uint64_t *ids, const double *values, u
  * node (:405-411), search checks the dimension even when empty (:416-421), rejects another metric with
  * VL_ERR_METRIC_MISMATCH (:425-430), walks the graph with ef = min(k, len) (:437,454), converts
  * u64 distances to scores (:51-75, :478-479), stable-sorts and truncates (:493-494).
- * The graph walk itself is this library's own (crate hnsw 0.11.0 is not part of the reference tree):
- * results are approximate and judged by recall. */
+ * The graph walk itself is this library's own (crate hnsw 0.11.0 is not part of the reference tree): it
+ * navigates by f32 distances and gives every node of the final beam the reference's exact f64 callback value,
+ * from which the returned scores are computed; results are approximate and judged by recall. */
 int vl_hnsw_create(uint64_t dim, int metric, int device, vl_index **out);
 int vl_hnsw_create_ex(uint64_t dim, int metric, uint32_t m, uint32_t m0, uint32_t ef_construction, uint64_t seed,
                       int device, vl_index **out);
@@ -217,10 +218,10 @@ int vl_index_force_path(vl_index *h, int path);
  * the exactness bound cannot certify the answer.  Results are identical either way. */
 int vl_index_set_single_filter(vl_index *h, int mode);
 
-/* Coalescing of concurrent vl_index_search calls on a flat index (the reference serves searches
+/* Coalescing of concurrent vl_index_search calls, flat or HNSW handle (the reference serves searches
  * concurrently under RwLock::read, src/client.rs:398; src/server.rs:269 -- one full scan each).
  * max_batch >= 2: callers that arrive while a scan is in flight are answered together by the next
- * slab pass (at most max_batch per pass; vl_index_search_batch's kernels); each caller still gets
+ * slab pass / graph-walk launch (at most max_batch per pass; vl_index_search_batch's kernels); each caller still gets
  * exactly the result and status a lone vl_index_search returns.  window_us > 0 additionally lets a
  * lone caller wait that long for company.  max_batch 0/1 = off (default).
  * vl_index_coalesce_stats: passes run and queries answered by them since creation. */
@@ -228,7 +229,8 @@ int vl_index_set_coalescing(vl_index *h, int max_batch, int window_us);
 int vl_index_coalesce_stats(const vl_index *h, uint64_t *batches, uint64_t *queries);
 
 /* HNSW handle: queries walked and Metric::distance evaluations (src/index/hnsw.rs:113-174) made for them since
- * creation.  Bytes touched per query = evaluations x dim x 8 (the walk reads the f64 master rows). */
+ * creation: navigation evaluations on the f32 rows (dim x 4 bytes each) plus one exact f64 evaluation per entry of
+ * the final beam (dim x 8 bytes each). */
 int vl_index_hnsw_walk_stats(const vl_index *h, uint64_t *queries, uint64_t *distance_evals);
 
 /* Kernel timing with HIP events on the stream the scan kernel runs on.

@@ -209,3 +209,43 @@ def test_walk_stats_count_distance_evaluations(V):
     idx.search(z[7], 5, V.SimilarityMetric.Euclidean)
     q2, e2 = idx.walk_stats()
     assert q2 == 51 and e2 > e
+
+
+def test_coalesced_concurrent_hnsw_searches_match_lone_searches(V):
+    """vl_index_set_coalescing on an HNSW handle: concurrent search() calls share walk launches and each
+    caller still gets exactly its lone-search result and status (walks are deterministic)."""
+    import threading
+    rng = np.random.default_rng(33)
+    n, dim = 20000, 48
+    z = rng.standard_normal((n, 8)) @ rng.standard_normal((8, dim))
+    idx = V.HNSWIndex(dim, V.SimilarityMetric.Cosine)
+    idx.add_rows(np.arange(n, dtype=np.uint64), z)
+    nq = 128
+    Q = z[rng.integers(0, n, nq)] + 0.01 * rng.standard_normal((nq, dim))
+    ks = [10 if i % 4 else 5 for i in range(nq)]
+    want = [[(r.id, r.score) for r in idx.search(Q[i], ks[i], V.SimilarityMetric.Cosine)] for i in range(nq)]
+    idx.set_coalescing(256, 200)
+    errors = []
+    bar = threading.Barrier(16)
+
+    def worker(t):
+        try:
+            bar.wait()
+            for i in range(t, nq, 16):
+                got = [(r.id, r.score) for r in idx.search(Q[i], ks[i], V.SimilarityMetric.Cosine)]
+                if got != want[i]:
+                    errors.append((t, i))
+            if t == 5:
+                with pytest.raises(V.MetricMismatch):
+                    idx.search(Q[0], 10, V.SimilarityMetric.Euclidean)
+                with pytest.raises(V.DimensionMismatch):
+                    idx.search(Q[0][:-1], 10, V.SimilarityMetric.Cosine)
+        except Exception as e:  # pragma: no cover
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert errors == []
+    batches, queries = idx.coalesce_stats()
+    assert queries == nq and batches < queries

@@ -58,7 +58,7 @@ def main():
         evq = (e1 - e0) / max(q1 - q0, 1)
         rec = np.mean([len(set(hi[i, :int(hnn[i])].tolist()) & set(ti[i].tolist())) / 10.0 for i in range(a.nq)])
         recq = np.mean([sum(1 for x in hi[i, :int(hnn[i])] if D[i][int(x)] <= kth[i]) / 10.0 for i in range(nchk)])
-        print(f"  ef={ef:4d}: recall@10 vs u64-distance order = {recq:.4f}  (vs exact f64 order {rec:.4f})   {a.nq/dt:9.0f} QPS (batch of {a.nq}); {evq:7.0f} distance evals/query = {evq * a.dim * 8 / 1e6:.2f} MB of rows/query, {(e1 - e0) / dt / 1e9:.2f} G evals/s = {(e1 - e0) * a.dim * 8 / dt / 1e12:.2f} TB/s of row reads")
+        print(f"  ef={ef:4d}: recall@10 vs u64-distance order = {recq:.4f}  (vs exact f64 order {rec:.4f})   {a.nq/dt:9.0f} QPS (batch of {a.nq}); {evq:7.0f} distance evals/query ({max(ef, 10)} of them exact f64) = {((evq - max(ef, 10)) * a.dim * 4 + max(ef, 10) * a.dim * 8) / 1e6:.2f} MB of rows/query, {(e1 - e0) / dt / 1e9:.2f} G evals/s = {(a.nq / dt) * ((evq - max(ef, 10)) * a.dim * 4 + max(ef, 10) * a.dim * 8) / 1e12:.2f} TB/s of row reads")
 
 if __name__ == "__main__":
     main()

@@ -397,6 +397,15 @@ class HNSWIndex:
                 pass
             self._h = None
 
+    def set_coalescing(self, max_batch: int, window_us: int = 0) -> None:
+        """Concurrent search() calls (other threads) share graph-walk launches; 0 turns it off."""
+        _raise(self._L.vl_index_set_coalescing(self._h, int(max_batch), int(window_us)))
+
+    def coalesce_stats(self) -> Tuple[int, int]:
+        b, q = C.c_uint64(0), C.c_uint64(0)
+        _raise(self._L.vl_index_coalesce_stats(self._h, C.byref(b), C.byref(q)))
+        return int(b.value), int(q.value)
+
     def walk_stats(self) -> Tuple[int, int]:
         """(queries walked, distance evaluations made for them) since creation."""
         a, b = C.c_uint64(0), C.c_uint64(0)

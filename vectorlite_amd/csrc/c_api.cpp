@@ -390,15 +390,17 @@ int vl_index_set_single_filter(vl_index* h, int mode)
 
 int vl_index_set_coalescing(vl_index* h, int max_batch, int window_us)
 {
-    if (!h || !h->flat || max_batch < 0 || window_us < 0) return VL_ERR_INVALID_ARG;
-    h->flat->set_coalescing(max_batch, window_us);
+    if (!h || max_batch < 0 || window_us < 0) return VL_ERR_INVALID_ARG;
+    if (h->hnsw) h->hnsw->set_coalescing(max_batch, window_us);
+    else h->flat->set_coalescing(max_batch, window_us);
     return VL_OK;
 }
 
 int vl_index_coalesce_stats(const vl_index* h, uint64_t* batches, uint64_t* queries)
 {
-    if (!h || !h->flat) return VL_ERR_INVALID_ARG;
-    h->flat->coalesce_stats(batches, queries);
+    if (!h) return VL_ERR_INVALID_ARG;
+    if (h->hnsw) h->hnsw->coalesce_stats(batches, queries);
+    else h->flat->coalesce_stats(batches, queries);
     return VL_OK;
 }
 

@@ -426,7 +426,7 @@ void GpuFlatIndex::profile_read(uint64_t* n, double* ms, uint64_t* bytes)
 int GpuFlatIndex::search(const double* query, uint64_t q_len, uint64_t k, int metric, uint64_t* out_pos,
                          uint64_t* out_ids, double* out_scores, uint64_t* out_n) const
 {
-    if (co_max_.load(std::memory_order_relaxed) > 1)
+    if (co_.enabled())
         return search_coalesced(query, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
     return search_direct(query, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
 }
@@ -441,20 +441,6 @@ int GpuFlatIndex::search(const double* query, uint64_t q_len, uint64_t k, int me
 // receives exactly what search_direct() would have returned (search_batch's contract); a batch that
 // fails as a whole (e.g. a NaN score for one member) is redone one by one so errors stay per caller.
 // ---------------------------------------------------------------------------------------------
-struct GpuFlatIndex::CoalesceReq {
-    const double* query;
-    uint64_t k;
-    int metric;
-    uint64_t* out_pos;
-    uint64_t* out_ids;
-    double* out_scores;
-    uint64_t* out_n;
-    int rc = OK;
-    int path = PATH_NONE;
-    std::string err;
-    bool done = false;
-};
-
 int GpuFlatIndex::search_coalesced(const double* query, uint64_t q_len, uint64_t k, int metric, uint64_t* out_pos,
                                    uint64_t* out_ids, double* out_scores, uint64_t* out_n) const
 {
@@ -469,40 +455,9 @@ int GpuFlatIndex::search_coalesced(const double* query, uint64_t q_len, uint64_t
     }
     {
         CoalesceReq r{query, k, metric, out_pos, out_ids, out_scores, out_n};
-        const size_t max_batch = (size_t)std::max(2, co_max_.load());
-        std::unique_lock<std::mutex> lk(co_mu_);
-        co_q_.push_back(&r);
-        co_cv_.notify_all();  // a leader waiting in its window counts arrivals
-        while (!r.done) {
-            if (co_leader_) {
-                co_cv_.wait(lk);
-                continue;
-            }
-            co_leader_ = true;
-            const int window = co_window_us_.load();
-            if (window > 0 && co_q_.size() < max_batch)
-                co_cv_.wait_for(lk, std::chrono::microseconds(window), [&] { return co_q_.size() >= max_batch; });
-            std::vector<CoalesceReq*> batch;
-            batch.push_back(&r);
-            for (auto it = co_q_.begin(); it != co_q_.end();) {
-                CoalesceReq* o = *it;
-                if (o == &r) {
-                    it = co_q_.erase(it);
-                } else if (o->metric == r.metric && o->k == r.k && batch.size() < max_batch) {
-                    batch.push_back(o);
-                    it = co_q_.erase(it);
-                } else {
-                    ++it;
-                }
-            }
-            lk.unlock();
-            run_coalesced(batch);
-            lk.lock();
-            for (CoalesceReq* o : batch) o->done = true;
-            co_leader_ = false;
-            co_cv_.notify_all();
-        }
-        lk.unlock();
+        co_.run(
+            r, [](const CoalesceReq& a, const CoalesceReq& o) { return a.metric == o.metric && a.k == o.k; },
+            [this](std::vector<CoalesceReq*>& batch) { run_coalesced(batch); });
         set_last_path(r.path);
         if (r.rc != OK) set_last_error(r.err);
         return r.rc;
@@ -513,8 +468,6 @@ direct:
 
 void GpuFlatIndex::run_coalesced(std::vector<CoalesceReq*>& batch) const
 {
-    co_batches_.fetch_add(1);
-    co_queries_.fetch_add(batch.size());
     auto one = [&](CoalesceReq* o) {
         o->rc = search_direct(o->query, dim_, o->k, o->metric, o->out_pos, o->out_ids, o->out_scores, o->out_n);
         o->path = last_path();

@@ -17,6 +17,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "coalescer.hpp"
 #include "kernels.hpp"
 #include "mfma_scan.hpp"
 
@@ -85,6 +86,20 @@ struct Workspace {
 
 class GpuFlatIndex {
 public:
+    struct CoalesceReq {  // one caller waiting in search_coalesced()
+        const double* query;
+        uint64_t k;
+        int metric;
+        uint64_t* out_pos;
+        uint64_t* out_ids;
+        double* out_scores;
+        uint64_t* out_n;
+        int rc = 0;
+        int path = 0;
+        std::string err;
+        bool done = false;
+    };
+
     // FlatIndex::new(dim, Vec::new())
     static int create(uint64_t dim, int device, GpuFlatIndex** out);
     ~GpuFlatIndex();
@@ -113,6 +128,9 @@ public:
 
     // storage access for the HNSW graph layered on top of this row store (hnsw_index.cpp)
     const double* device_master() const { return d_master_; }
+    const float* device_slab() const { return d_slab_; }
+    const float* device_inv_norm() const { return d_inv_norm_; }
+    uint32_t slab_ld() const { return ld_; }
     uint64_t capacity() const { return cap_; }
 
     void force_path(int p) { force_path_.store(p); }
@@ -123,18 +141,10 @@ public:
         bf16_tries_.store(0);
         bf16_fails_.store(0);
     }
-    // Group concurrent single-query search() calls into shared slab passes (see search_coalesced()).
+    // Group concurrent single-query search() calls into shared slab passes (coalescer.hpp, search_coalesced()).
     // max_batch <= 1 turns it off (default).  window_us: how long a lone caller waits for company.
-    void set_coalescing(int max_batch, int window_us)
-    {
-        co_window_us_.store(window_us < 0 ? 0 : window_us);
-        co_max_.store(max_batch < 0 ? 0 : (max_batch > (int)MFMA_MAX_BATCH ? (int)MFMA_MAX_BATCH : max_batch));
-    }
-    void coalesce_stats(uint64_t* batches, uint64_t* queries) const
-    {
-        if (batches) *batches = co_batches_.load();
-        if (queries) *queries = co_queries_.load();
-    }
+    void set_coalescing(int max_batch, int window_us) { co_.configure(max_batch, window_us, (int)MFMA_MAX_BATCH); }
+    void coalesce_stats(uint64_t* batches, uint64_t* queries) const { co_.stats(batches, queries); }
     void profile_enable(bool on);
     void profile_read(uint64_t* n, double* ms, uint64_t* bytes);
     int device() const { return device_; }
@@ -148,7 +158,6 @@ private:
     Workspace* acquire_ws() const;
     void release_ws(Workspace* ws) const;
     int prepare_ws(Workspace* ws) const;
-    struct CoalesceReq;
     int search_direct(const double* query, uint64_t q_len, uint64_t k, int metric, uint64_t* out_pos, uint64_t* out_ids,
                       double* out_scores, uint64_t* out_n) const;
     int search_coalesced(const double* query, uint64_t q_len, uint64_t k, int metric, uint64_t* out_pos,
@@ -198,13 +207,7 @@ private:
     mutable std::vector<Workspace*> ws_free_;
     mutable std::vector<std::unique_ptr<Workspace>> ws_all_;
 
-    // coalescing queue (leader/follower: the caller that finds no batch in flight runs the next one)
-    mutable std::mutex co_mu_;
-    mutable std::condition_variable co_cv_;
-    mutable std::deque<CoalesceReq*> co_q_;
-    mutable bool co_leader_ = false;
-    std::atomic<int> co_max_{0}, co_window_us_{0};
-    mutable std::atomic<uint64_t> co_batches_{0}, co_queries_{0};
+    mutable Coalescer<CoalesceReq> co_;
 
     std::atomic<int> force_path_{0};
     std::atomic<int> single_filter_{0};

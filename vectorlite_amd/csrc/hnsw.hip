@@ -3,10 +3,14 @@
 // and what is our own (the walk: parity with crate hnsw 0.11.0 is unpinned).
 //
 // One WAVE per query / per inserted node:
-//   * the query sits in LDS as f64; a hop loads the <= 32 neighbour ids of the expanded node with
-//     one coalesced load, filters them through a per-wave visited-stamp array in HBM, and each
-//     surviving lane walks ITS neighbour's f64 row in index order (separate multiply and add) to
-//     produce the reference's u64 distance -- the per-hop distance kernel of north_star;
+//   * a hop loads the <= 32 neighbour ids of the expanded node with one coalesced load and filters them
+//     through a per-wave visited-stamp array in HBM;
+//   * BUILD walks evaluate every surviving neighbour with the reference's callback: one lane walks one f64
+//     row in index order (separate multiply and add) -- the edge distances stored in the graph are exact;
+//   * QUERY walks navigate by f32 distances (two lanes per neighbour on the flat scan's f32 slab: half the
+//     bytes, half the serial length, 3x lower single-query latency) and then give every node of the final
+//     beam the exact f64 callback value -- the per-hop distance kernel of north_star -- from which the
+//     returned distances and scores are computed;
 //   * the beam (result list + frontier in one) is a sorted list held one or two entries per lane,
 //     updated with ballot / DPP shifts like the flat scan's top-k list.
 #include "hnsw.hpp"
@@ -202,6 +206,95 @@ __device__ __forceinline__ void beam_layer(const HnswGraphView& g, const double*
     }
 }
 
+// Navigation distance of the QUERY walk: two lanes share one neighbour's f32 slab row (alternating
+// 16-byte chunks, the f32 query in LDS), partial sums joined across the half-waves.  Half the bytes of
+// the f64 row and 1/2 of its serial length per lane; the result orders candidates far more finely than
+// the reference's own distance does (it truncates to 1e-3), and every node that reaches the final beam
+// gets the exact callback value afterwards (k_hnsw_search).
+template <int METRIC>
+__device__ __forceinline__ unsigned long long row_distance_f32(const HnswGraphView& g, uint32_t node, const float* q32,
+                                                               float q_inv, int half)
+{
+    const f32x4* row = reinterpret_cast<const f32x4*>(g.slab + (size_t)node * g.ld);
+    const f32x4* q4 = reinterpret_cast<const f32x4*>(q32);
+    const uint32_t ld4 = g.ld / 4;
+    float s = 0.f;
+    auto step = [&](const f32x4 x, const f32x4 y) {
+        if (METRIC == COSINE || METRIC == DOT) {
+            s = fmaf(x.x, y.x, s); s = fmaf(x.y, y.y, s); s = fmaf(x.z, y.z, s); s = fmaf(x.w, y.w, s);
+        } else if (METRIC == EUCLIDEAN) {
+            const float a = x.x - y.x, b = x.y - y.y, c = x.z - y.z, d = x.w - y.w;
+            s = fmaf(a, a, s); s = fmaf(b, b, s); s = fmaf(c, c, s); s = fmaf(d, d, s);
+        } else {
+            s += fabsf(x.x - y.x) + fabsf(x.y - y.y) + fabsf(x.z - y.z) + fabsf(x.w - y.w);
+        }
+    };
+    uint32_t c = (uint32_t)half;
+    for (; c + 14 < ld4; c += 16) {  // 8 loads in flight per lane
+        f32x4 x[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] = row[c + 2 * t];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) step(x[t], q4[c + 2 * t]);
+    }
+    for (; c < ld4; c += 2) step(row[c], q4[c]);
+    s += __shfl_xor(s, 32);
+    double scaled;
+    if (METRIC == COSINE) {
+        const float rinv = g.inv_norm[node];
+        scaled = (rinv == 0.f || q_inv == 0.f) ? 1000.0 : (1.0 - (double)(s * rinv * q_inv)) * 1000.0;
+    } else if (METRIC == EUCLIDEAN) {
+        scaled = (double)sqrtf(s) * 1000.0;
+    } else if (METRIC == MANHATTAN) {
+        scaled = (double)s * 1000.0;
+    } else {
+        float d = s;
+        d = d < -1000.f ? -1000.f : (d > 1000.f ? 1000.f : d);
+        scaled = 1000.0 - (double)d;
+    }
+    return walk_key(scaled);
+}
+
+// beam_layer with f32 navigation distances: lanes l and l + 32 serve neighbour l of the expanded node
+// (rounds of 32 neighbours when a list is longer).
+template <int METRIC, int S>
+__device__ __forceinline__ void beam_layer_f32(const HnswGraphView& g, const float* q32, float q_inv, int layer,
+                                               uint32_t* stamps, uint32_t epoch, BeamList<S>& L, int ef, uint32_t* evals)
+{
+    const int lane = lane_id();
+    const int half = lane >> 5, nl = lane & 31;
+    for (;;) {
+        const int idx = L.next_unexpanded();
+        if (idx < 0) break;
+        unsigned long long dc;
+        uint32_t c;
+        L.get(idx, dc, c);
+        L.mark_expanded(idx);
+        const LayerView lv = layer_of(g, c, layer);
+        for (uint32_t base = 0; base < lv.cnt; base += 32) {
+            uint32_t e = base + (uint32_t)nl < lv.cnt ? lv.nbr[base + nl] : HNSW_NONE;
+            bool act = e != HNSW_NONE;
+            if (act && half == 0) {
+                if (stamps[e] == epoch) act = false;
+                else stamps[e] = epoch;
+            }
+            act = __shfl((int)act, nl) != 0;  // the upper half-wave follows its partner's visited check
+            unsigned long long de = ~0ull;
+            if (act) de = row_distance_f32<METRIC>(g, e, q32, q_inv, half);
+            *evals += (uint32_t)__popcll(__ballot(act && half == 0));
+            unsigned long long w;
+            uint32_t wn;
+            L.get(ef - 1, w, wn);
+            unsigned long long m = __ballot(act && half == 0 && (wn == HNSW_NONE || de <= w));
+            while (m) {
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+                m &= m - 1;
+                L.insert(read_lane(de, src), read_lane(e, src), ef);
+            }
+        }
+    }
+}
+
 // Move to the next layer: keep the entries as entry points, fresh visited epoch.
 template <int S>
 __device__ __forceinline__ void next_layer(BeamList<S>& L, uint32_t* stamps, uint32_t& epoch)
@@ -218,45 +311,64 @@ __global__ __launch_bounds__(256) void k_hnsw_search(HnswGraphView g, const doub
                                                      uint32_t ef, uint32_t entry, int max_level,
                                                      HnswHit* __restrict__ out)
 {
-    extern __shared__ double q_lds[];  // [4][dim]
+    extern __shared__ double q_lds[];  // per wave: [dim] f64 query, then [ld] f32 copy (zero padded)
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const uint32_t slot = blockIdx.x * 4 + wave;
     if (slot >= g.n_slots) return;
-    double* q = q_lds + (size_t)wave * g.dim;
+    const size_t per_wave = ((size_t)g.ld / 2 + g.dim + 1) & ~(size_t)1;  // in doubles, 16-byte granules
+    float* q32 = reinterpret_cast<float*>(q_lds + (size_t)wave * per_wave);
+    double* q = q_lds + (size_t)wave * per_wave + g.ld / 2;
     uint32_t* stamps = g.stamps + (size_t)slot * g.cap;
     uint32_t epoch = g.epochs[slot];
 
     for (uint32_t qi = slot; qi < nq; qi += gridDim.x * 4) {
-        for (uint32_t i = lane; i < g.dim; i += 64) q[i] = queries[(size_t)qi * g.dim + i];
+        float qq = 0.f;
+        for (uint32_t i = lane; i < g.ld; i += 64) {
+            const double v = i < g.dim ? queries[(size_t)qi * g.dim + i] : 0.0;
+            if (i < g.dim) q[i] = v;
+            q32[i] = (float)v;
+            qq = fmaf((float)v, (float)v, qq);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) qq += __shfl_xor(qq, o);
+        const float q_inv = qq > 0.f ? 1.0f / sqrtf(qq) : 0.f;
         __builtin_amdgcn_wave_barrier();
         BeamList<S> L;
         L.init();
         epoch += 1;
         uint32_t evals = 1;  // the entry point
         {
-            unsigned long long d0 = 0;
-            if (lane == 0) d0 = row_distance<METRIC>(g.master + (size_t)entry * g.dim, q, g.dim);
+            unsigned long long d0 = row_distance_f32<METRIC>(g, entry, q32, q_inv, lane >> 5);
             d0 = read_lane(d0, 0);
             L.insert(d0, entry, 1);
             if (lane == 0) stamps[entry] = epoch;
         }
         for (int layer = max_level; layer >= 1; --layer) {
-            beam_layer<METRIC, S>(g, q, layer, stamps, epoch, L, 1, &evals);
+            beam_layer_f32<METRIC, S>(g, q32, q_inv, layer, stamps, epoch, L, 1, &evals);
             next_layer(L, stamps, epoch);
         }
-        beam_layer<METRIC, S>(g, q, 0, stamps, epoch, L, (int)ef, &evals);
+        beam_layer_f32<METRIC, S>(g, q32, q_inv, 0, stamps, epoch, L, (int)ef, &evals);
+        // the final beam gets the reference's own callback value: one lane walks one f64 row in index order
+        // (src/index/hnsw.rs:113-174); the host orders the beam by it
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const uint32_t j = s * 64 + lane;
+            const uint32_t node = L.v[s] == HNSW_NONE ? HNSW_NONE : (L.v[s] & ~EXPANDED);
+            unsigned long long exact = ~0ull;
+            const bool real = j < ef && node != HNSW_NONE;
+            if (real) exact = row_distance<METRIC>(g.master + (size_t)node * g.dim, q, g.dim);
+            evals += (uint32_t)__popcll(__ballot(real));
             if (j < ef) {
                 HnswHit h;
-                h.dist = walk_key_to_u64(L.d[s]);  // the reference's u64 distance
-                h.node = L.v[s] == HNSW_NONE ? HNSW_NONE : (L.v[s] & ~EXPANDED);
-                h.evals = j == 0 ? evals : 0u;
+                h.dist = exact;  // bit pattern of the reference's f64 value BEFORE its `as u64`: the host orders by it, then truncates
+                h.node = node;
+                h.evals = 0u;
                 out[(size_t)qi * ef + j] = h;
             }
         }
+        if (lane == 0) out[(size_t)qi * ef].evals = evals;
+        __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) g.epochs[slot] = epoch;
 }
@@ -480,7 +592,7 @@ hipError_t launch_hnsw_search(hipStream_t s, int metric, const HnswGraphView& g,
 {
     if (nq == 0) return hipSuccess;
     if (ef == 0 || ef > (uint32_t)HNSW_MAX_EF || g.m0 > 64 || g.m > 64) return hipErrorInvalidValue;
-    const size_t lds = (size_t)4 * g.dim * sizeof(double);
+    const size_t lds = (size_t)4 * ((((size_t)g.ld / 2 + g.dim + 1) & ~(size_t)1)) * sizeof(double);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     const int grid = grid_for(g, nq);
     return dispatch_metric(metric, [&](auto M) -> hipError_t {

@@ -20,6 +20,9 @@ constexpr int HNSW_MAX_LEVEL = 15;
 
 struct HnswGraphView {
     const double* master;  // [cap, dim] f64 rows (node index = storage position)
+    const float* slab;     // [cap, ld] f32 copy of the rows (the flat scan's slab): navigation distances of the query walk
+    const float* inv_norm; // [cap] f32 1/|row| (0 for zero rows)
+    uint32_t ld;           // slab row stride in floats (dim rounded up to 4)
     uint32_t dim;
     uint32_t m, m0;        // max neighbours per node: upper layers / layer 0
     // layer 0
@@ -41,7 +44,7 @@ struct HnswGraphView {
 };
 
 struct HnswHit {  // one neighbour returned by a walk
-    unsigned long long dist;  // Metric::distance(query, node) as the reference defines it
+    unsigned long long dist;  // query walk: f64 bit pattern of Metric::distance's value before `as u64` (~0 = empty slot)
     uint32_t node;
     uint32_t evals;  // entry 0 of a query: distance evaluations of the whole walk; else 0
 };

@@ -130,6 +130,9 @@ HnswGraphView HnswIndex::view() const
 {
     HnswGraphView g;
     g.master = store_->device_master();
+    g.slab = store_->device_slab();
+    g.inv_norm = store_->device_inv_norm();
+    g.ld = store_->slab_ld();
     g.dim = (uint32_t)dim_;
     g.m = params_.m;
     g.m0 = params_.m0;
@@ -426,10 +429,60 @@ int HnswIndex::ensure_search_scratch(uint64_t nq, uint32_t ef) const
     return OK;
 }
 
+namespace {
+// Rust `f64 as u64` (truncation toward zero, saturating, NaN -> 0) of the f64 whose bits are `key`
+uint64_t rust_as_u64_host(uint64_t key)
+{
+    double v;
+    std::memcpy(&v, &key, sizeof v);
+    if (!(v > 0.0)) return 0;
+    if (v >= 18446744073709551616.0) return ~0ull;
+    return (uint64_t)v;
+}
+}  // namespace
+
 int HnswIndex::search(const double* query, uint64_t q_len, uint64_t k, int metric, uint32_t ef, uint64_t* out_ids,
                       double* out_scores, uint64_t* out_n) const
 {
-    return search_batch(query, 1, q_len, k, metric, ef, out_ids, out_scores, out_n);
+    // Walks of one index run one launch at a time (shared visited stamps), so concurrent callers gain nothing
+    // from more threads -- unless their queries share a launch.  Everything that can fail without walking is
+    // settled on the calling thread; compatible requests (same k and ef; the metric is the index's) are walked
+    // by one search_batch(), each caller receiving exactly what its own search_batch(nq = 1) would return.
+    if (!co_.enabled() || !out_n || q_len != dim_ || metric != metric_ || k == 0 || !query || !out_ids || !out_scores ||
+        k > (uint64_t)HNSW_MAX_EF)
+        return search_batch(query, 1, q_len, k, metric, ef, out_ids, out_scores, out_n);
+    CoalesceReq r{query, k, ef, out_ids, out_scores, out_n};
+    co_.run(
+        r, [](const CoalesceReq& a, const CoalesceReq& o) { return a.k == o.k && a.ef == o.ef; },
+        [this](std::vector<CoalesceReq*>& batch) {
+            const uint64_t nq = batch.size(), kk = batch[0]->k;
+            int rc = OK;
+            if (nq > 1) {
+                std::vector<double> q(nq * dim_);
+                for (uint64_t i = 0; i < nq; ++i) std::memcpy(q.data() + i * dim_, batch[i]->query, dim_ * sizeof(double));
+                std::vector<uint64_t> ids(nq * kk), cnt(nq);
+                std::vector<double> scores(nq * kk);
+                rc = search_batch(q.data(), nq, dim_, kk, metric_, batch[0]->ef, ids.data(), scores.data(), cnt.data());
+                if (rc == OK) {
+                    for (uint64_t i = 0; i < nq; ++i) {
+                        CoalesceReq* o = batch[i];
+                        for (uint64_t j = 0; j < cnt[i]; ++j) {
+                            o->out_ids[j] = ids[i * kk + j];
+                            o->out_scores[j] = scores[i * kk + j];
+                        }
+                        *o->out_n = cnt[i];
+                        o->rc = OK;
+                    }
+                    return;
+                }
+            }
+            for (CoalesceReq* o : batch) {  // alone, or the batch failed as a whole: per-caller status
+                o->rc = search_batch(o->query, 1, dim_, o->k, metric_, o->ef, o->out_ids, o->out_scores, o->out_n);
+                if (o->rc != OK) o->err = last_error();
+            }
+        });
+    if (r.rc != OK) set_last_error(r.err);
+    return r.rc;
 }
 
 int HnswIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_len, uint64_t k, int metric, uint32_t ef,
@@ -481,8 +534,16 @@ int HnswIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_len, 
     stat_queries_.fetch_add(nq, std::memory_order_relaxed);
     for (uint64_t qi = 0; qi < nq; ++qi) {
         res.clear();
-        const HnswHit* hits = h_hits_ + qi * ef_walk;
+        HnswHit* hits = h_hits_ + qi * ef_walk;
         stat_evals_.fetch_add(hits[0].evals, std::memory_order_relaxed);
+        // The walk navigates by f32 distances and re-evaluates the final beam with the reference's f64
+        // callback (value before its `as u64`): put the beam into (distance, node) order -- a refinement of the
+        // order `neighbors` has after hnsw.nearest (:454-466), ties of the truncated value broken by the true
+        // distance -- before the closest max_candidates are taken.
+        std::sort(hits, hits + ef_walk, [](const HnswHit& a, const HnswHit& b) {
+            if ((a.node == HNSW_NONE) != (b.node == HNSW_NONE)) return b.node == HNSW_NONE;
+            return a.dist < b.dist || (a.dist == b.dist && a.node < b.node);
+        });
         // `neighbors` holds max_candidates slots (:442-448): the walk's closest max_candidates
         for (uint64_t i = 0; i < ef_walk && res.size() < max_candidates; ++i) {
             const HnswHit& h = hits[i];
@@ -492,7 +553,7 @@ int HnswIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_len, 
                 return ERR_DEVICE;
             }
             if (!live_[h.node]) continue;             // :475 tombstoned nodes are dropped AFTER the walk
-            res.push_back({node_id_[h.node], hnsw_score(h.dist, metric_)});
+            res.push_back({node_id_[h.node], hnsw_score(rust_as_u64_host(h.dist), metric_)});
         }
         // Note: like the reference, tombstones can make fewer than k results come back.  Unlike the
         // reference the slots freed by tombstones are refilled from the rest of the beam when ef > k.

@@ -8,6 +8,7 @@
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
@@ -28,6 +29,21 @@ struct HnswParams {
 
 class HnswIndex {
 public:
+    struct CoalesceReq {  // one caller waiting in search() while coalescing is on
+        const double* query;
+        uint64_t k;
+        uint32_t ef;
+        uint64_t* out_ids;
+        double* out_scores;
+        uint64_t* out_n;
+        int rc = 0;
+        std::string err;
+        bool done = false;
+    };
+    // concurrent single-query search() calls share walk launches (coalescer.hpp); 0 / 1 = off (default)
+    void set_coalescing(int max_batch, int window_us) { co_.configure(max_batch, window_us, 4096); }
+    void coalesce_stats(uint64_t* batches, uint64_t* queries) const { co_.stats(batches, queries); }
+
     static int create(uint64_t dim, int metric, const HnswParams& p, int device, HnswIndex** out);
     ~HnswIndex();
 
@@ -48,7 +64,7 @@ public:
     // #[derive(Clone)] on HNSWIndex (persistence clones the wrapper, src/persistence.rs:118): a deep copy of
     // the rows and of the device graph, tombstones included.
     // queries walked and Metric::distance evaluations made by them since creation (SURVEY 8(d) C4:
-    // bytes touched per query = evaluations x dim x 8, the f64 master rows the walk reads)
+    // navigation evaluations read f32 rows, the final beam's exact evaluations f64 rows)
     void walk_stats(uint64_t* queries, uint64_t* distance_evals) const;
     int clone(HnswIndex** out) const;
     // live rows in node (insertion) order: the `vector_values` member of the serialised form
@@ -97,6 +113,7 @@ private:
     uint64_t live_count_ = 0;
 
     mutable std::atomic<uint64_t> stat_queries_{0}, stat_evals_{0};
+    mutable Coalescer<CoalesceReq> co_;
 
     // search scratch
     mutable double* d_q_ = nullptr;
