@@ -498,29 +498,61 @@ __global__ __launch_bounds__(256) void k_exact_scan(const double* __restrict__ m
                                                     const double* __restrict__ q64, uint64_t n, uint32_t dim,
                                                     double* __restrict__ scores, uint32_t* __restrict__ nan_flag)
 {
+    // One thread owns one row and walks it in index order (the reference's serial f64 chains), so the rows
+    // of a tile are transposed through LDS: 16 consecutive threads fetch one row's 128-byte line, then each
+    // thread reads its own row from the padded tile.  The next chunk's loads are issued into registers
+    // BEFORE the current chunk's arithmetic, so HBM latency hides behind the 16 dependent steps.
     __shared__ double tile[EX_ROWS][EX_CH + 1];
     __shared__ double qtile[EX_CH];
     const int tid = threadIdx.x;
     const uint64_t n_tiles = (n + EX_ROWS - 1) / EX_ROWS;
+    const uint32_t n_chunks = (dim + EX_CH - 1) / EX_CH;
     for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint64_t row0 = t * EX_ROWS;
         const uint64_t rows_here = (n - row0) < (uint64_t)EX_ROWS ? (n - row0) : (uint64_t)EX_ROWS;
         Acc64<METRIC> A;
         A.init();
-        for (uint32_t c0 = 0; c0 < dim; c0 += EX_CH) {
+        double pre[EX_CH];
+        double qpre = 0.0;
+        auto fetch = [&](uint32_t c0) {
             const uint32_t cw = (dim - c0) < (uint32_t)EX_CH ? (dim - c0) : (uint32_t)EX_CH;
-            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < EX_CH; ++i) {
+                // clamped, never predicated: a load under a condition makes hipcc wait for each one in turn;
+                // rows >= rows_here are never walked and columns >= cw never stepped, so duplicates are harmless
+                const int idx = tid + i * 256;
+                uint64_t r = (uint64_t)(idx / EX_CH);
+                uint32_t cc = (uint32_t)(idx % EX_CH);
+                r = r < rows_here ? r : rows_here - 1;
+                cc = cc < cw ? cc : cw - 1;
+                pre[i] = master[(row0 + r) * dim + c0 + cc];
+            }
+            {
+                uint32_t qc = (uint32_t)(tid % EX_CH);
+                qc = qc < cw ? qc : cw - 1;
+                qpre = q64[c0 + qc];
+            }
+        };
+        fetch(0);
+        for (uint32_t ch = 0; ch < n_chunks; ++ch) {
+            const uint32_t c0 = ch * EX_CH;
+            const uint32_t cw = (dim - c0) < (uint32_t)EX_CH ? (dim - c0) : (uint32_t)EX_CH;
+            __syncthreads();  // the previous chunk's readers are done with the tile
 #pragma unroll
             for (int i = 0; i < EX_CH; ++i) {
                 const int idx = tid + i * 256;
-                const int r = idx / EX_CH, cc = idx % EX_CH;
-                if ((uint64_t)r < rows_here && (uint32_t)cc < cw)
-                    tile[r][cc] = master[(row0 + r) * dim + c0 + cc];
+                tile[idx / EX_CH][idx % EX_CH] = pre[i];
             }
-            if (tid < EX_CH && (uint32_t)tid < cw) qtile[tid] = q64[c0 + tid];
+            if (tid < EX_CH) qtile[tid] = qpre;
             __syncthreads();
+            if (ch + 1 < n_chunks) fetch(c0 + EX_CH);  // in flight during the arithmetic below
             if ((uint64_t)tid < rows_here) {
-                for (uint32_t cc = 0; cc < cw; ++cc) A.step(tile[tid][cc], qtile[cc]);
+                if (cw == (uint32_t)EX_CH) {
+#pragma unroll
+                    for (uint32_t cc = 0; cc < (uint32_t)EX_CH; ++cc) A.step(tile[tid][cc], qtile[cc]);
+                } else {
+                    for (uint32_t cc = 0; cc < cw; ++cc) A.step(tile[tid][cc], qtile[cc]);
+                }
             }
         }
         if ((uint64_t)tid < rows_here) {
