@@ -793,3 +793,24 @@ def test_stateful_fuzz_large_index_all_filters(V, O):
         for j in range(12):
             want = ref.search(Q[j], k, m)
             assert bi[j, : bn[j]].tolist() == want[0].tolist() and bs[j, : bn[j]].tolist() == want[1].tolist(), (step, j, m, k)
+
+
+def test_exact_select_rounds_for_k_above_64(V, O):
+    """64 < k <= 1024 on a large enough index: rounds of 64, each restricted to the rows behind the previous
+    round's last entry; duplicated rows straddle the round boundaries (ties resolved by position)."""
+    rng = np.random.default_rng(5150)
+    n, dim = 600_000, 16
+    rows = unit_rows(rng, n, dim)
+    rows[1000:1200] = rows[999]      # 201 identical rows: equal scores across several round boundaries
+    ids = permuted_ids(n)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    q = rows[999] + 0.001 * rng.standard_normal(dim)
+    for m in (0, 1, 3):
+        for k in (65, 128, 129, 200):
+            assert_same(V, gpu.search_arrays(q, k, m), ref.search(q, k, m), (m, k))
+            # 600 k rows allow 2 rounds (a round is cheaper than the sort only on big indexes, flat_index.cpp)
+            assert V.last_path() == (V.PATH_EXACT_SELECT if k <= 128 else V.PATH_EXACT_SORT)
+    assert_same(V, gpu.search_arrays(q, 1000, 0), ref.search(q, 1000, 0), "k=1000")
+    assert V.last_path() == V.PATH_EXACT_SORT

@@ -20,11 +20,11 @@ for n in (1_000, 100_000, 1_000_000, 10_000_000):
         x /= torch.linalg.vector_norm(x, dim=1, keepdim=True)
         idx.add_rows(np.arange(c0, c0 + c, dtype=np.uint64), x, validate=False)
         del x
-    for k in (10, 48, 64, 100, 1000):
+    for k in (10, 48, 60, 64, 100, 1000, 2000):
         if k > n:
             continue
         reps = 40 if k <= 48 else 6
-        for i in range(3):
+        for i in range(12):
             idx.search_arrays(Q[i], k, 0)
         t = time.perf_counter()
         for i in range(reps):

@@ -564,7 +564,10 @@ __global__ __launch_bounds__(256) void k_exact_scan(const double* __restrict__ m
 }
 
 // top-64 of scores[] by (score desc, pos asc): per-wave lists, then per-workgroup merge
+// `after` (optional): the result block of the previous round; only rows ranked strictly behind its last
+// entry are offered, so round r yields ranks 64 r .. 64 r + 63 of the full (score desc, pos asc) order.
 __global__ __launch_bounds__(256) void k_select64(const double* __restrict__ scores, uint32_t n,
+                                                  const SearchResultBlock* __restrict__ after,
                                                   Cand64* __restrict__ out)
 {
     __shared__ Cand64 sh[4 * WAVE];
@@ -574,10 +577,14 @@ __global__ __launch_bounds__(256) void k_select64(const double* __restrict__ sco
     const uint32_t n_waves = gridDim.x * 4;
     TopList<double> L;
     L.init();
+    const bool cut = after != nullptr;
+    const double cut_key = cut ? after->score[KP - 1] : 0.0;
+    const uint32_t cut_pos = cut ? after->pos[KP - 1] : 0u;
     for (uint32_t s = blockIdx.x * 4 + wave; s < n_steps; s += n_waves) {
         const uint32_t row = s * WAVE + lane;
-        const bool valid = row < n;
+        bool valid = row < n;
         const double sc = valid ? scores[row] : 0.0;
+        if (cut) valid = valid && better<double>(cut_key, cut_pos, sc, row);
         L.offer(sc, row, valid);
     }
     block_merge<double, Cand64, 4>(L, sh);
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(1024) void k_merge64_emit(const Cand64* __restrict_
     block_merge<double, Cand64, NW>(L, sh);
     if (wave == 0) {
         const uint32_t k_eff = (uint64_t)k < n_rows ? k : (uint32_t)n_rows;
-        if ((uint32_t)lane < k_eff) {
+        if ((uint32_t)lane < k_eff || k == (uint32_t)KP) {  // a full round also carries its cut entry for the next one
             out->pos[lane] = L.pos;
             out->score[lane] = L.key;
         }
@@ -1097,11 +1104,11 @@ int select_grid_for(uint64_t n)
 }
 
 hipError_t launch_exact_select(hipStream_t s, const double* scores, uint64_t n, uint32_t k, Cand64* partials,
-                               const uint32_t* nan_flag, SearchResultBlock* out)
+                               const uint32_t* nan_flag, SearchResultBlock* out, const SearchResultBlock* after)
 {
     if (n == 0 || n >= 0xFFFFFFFFull || k > (uint32_t)KP) return hipErrorInvalidValue;
     const int grid = select_grid_for(n);
-    hipLaunchKernelGGL(k_select64, dim3(grid), dim3(256), 0, s, scores, (uint32_t)n, partials);
+    hipLaunchKernelGGL(k_select64, dim3(grid), dim3(256), 0, s, scores, (uint32_t)n, after, partials);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     int n_lists = grid;

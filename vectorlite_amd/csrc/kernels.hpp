@@ -95,8 +95,11 @@ hipError_t launch_exact_scan(hipStream_t s, int metric, const double* master, co
                              uint32_t dim, double* scores, uint32_t* nan_flag);
 // Exact path, k <= KP: top-k of scores[] by (score desc, pos asc).
 int select_grid_for(uint64_t n);
+// Ranks 64 r .. 64 r + k - 1 of the exact order: `after` = the (full, k = 64) block of round r - 1, nullptr for r = 0.
 hipError_t launch_exact_select(hipStream_t s, const double* scores, uint64_t n, uint32_t k, Cand64* partials,
-                               const uint32_t* nan_flag, SearchResultBlock* out);
+                               const uint32_t* nan_flag, SearchResultBlock* out,
+                               const SearchResultBlock* after = nullptr);
+constexpr int SELECT_MAX_ROUNDS = 16;  // k <= 1024 is answered by rounds of 64; larger k by the full sort
 // Exact path, any k: device-wide sort of (score desc, pos asc); writes the first k.
 // okeys/opos are scratch of next_pow2(n) entries.
 uint64_t sort_capacity_for(uint64_t n);
