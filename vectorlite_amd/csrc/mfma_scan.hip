@@ -4,13 +4,14 @@
 // queries per slab pass the scan stops being HBM-bound, so scores[row, query] are
 // computed on the matrix cores: v_mfma_f32_32x32x16_bf16, rows as the A operand (streamed through
 // LDS, one contiguous 32-row tile at a time), 32 queries per wave as the B operand held in registers
-// for the whole launch (128 queries per workgroup share every row tile).
+// for the whole launch (256 queries per 8-wave workgroup share every row tile).
 //
 // bf16 scores are only a CANDIDATE FILTER.  The Q x N score matrix is never written:
-//   pass 0 (a 1/16 sample of the rows): every workgroup reports, per query, the best key of its
+//   pass 0 (a sample: 1/16 of the rows, at least 65536 of them): every workgroup reports, per query, the best key of its
 //     own set of row tiles; the 64th largest of those maxima is a valid lower bound T_q of the
 //     query's 64th best key (64 distinct rows reach it);
-//   pass 1 (all rows): keys >= T_q are appended to the query's candidate buffer (about 10^3 of 10^7);
+//   pass 1 (all rows, in three stages of growing size; between stages T_q is raised to the 64th best
+//     candidate found so far): keys >= T_q are appended to the query's candidate buffer (a few hundred of 10^7);
 //   then per query: top-64 of the buffer -> the same finalize kernel as the f32 path: exact f64
 //     rescoring from the master rows, (score desc, position asc) ranking and the bound check, now
 //     with the bf16 input-rounding term (2^-8 relative per operand) in the bound.
