@@ -101,12 +101,18 @@ __device__ __forceinline__ float scan_key(float sum, float inv_norm)
 // (slab padding) read as zero.
 __device__ __forceinline__ f32x4 load_q4(const double* __restrict__ q64, uint32_t j4, uint32_t dim)
 {
-    const uint32_t i = j4 * 4;
+    // Clamped, never predicated: `i < dim ? q64[i] : 0` makes hipcc branch around every load and wait for
+    // each in turn (48 dependent L2 round trips in the prologue of every wave of the dim-384 scan).
+    const uint32_t i = j4 * 4, last = dim - 1;
+    const double v0 = q64[i + 0 < dim ? i + 0 : last];
+    const double v1 = q64[i + 1 < dim ? i + 1 : last];
+    const double v2 = q64[i + 2 < dim ? i + 2 : last];
+    const double v3 = q64[i + 3 < dim ? i + 3 : last];
     f32x4 r;
-    r.x = i + 0 < dim ? (float)q64[i + 0] : 0.0f;
-    r.y = i + 1 < dim ? (float)q64[i + 1] : 0.0f;
-    r.z = i + 2 < dim ? (float)q64[i + 2] : 0.0f;
-    r.w = i + 3 < dim ? (float)q64[i + 3] : 0.0f;
+    r.x = i + 0 < dim ? (float)v0 : 0.0f;
+    r.y = i + 1 < dim ? (float)v1 : 0.0f;
+    r.z = i + 2 < dim ? (float)v2 : 0.0f;
+    r.w = i + 3 < dim ? (float)v3 : 0.0f;
     return r;
 }
 
@@ -310,6 +316,7 @@ __device__ __forceinline__ void rescore_rows(const double* __restrict__ master, 
     constexpr int PF = (NTHREADS >= 1024) ? 4 : 1;
     const int tid = threadIdx.x;
     A.init();
+    if (n_rows <= 0) return;  // workgroup-uniform (an all-sentinel candidate list)
     for (uint32_t g0 = 0; g0 < dim; g0 += PF * RESCORE_CH) {
         double pre[PF][PER];
         double qpre[PF];
@@ -318,13 +325,21 @@ __device__ __forceinline__ void rescore_rows(const double* __restrict__ master, 
             const uint32_t c0 = g0 + p * RESCORE_CH;
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
-                const int idx = tid + i * NTHREADS;
-                const int r = idx / RESCORE_CH, cc = idx % RESCORE_CH;
-                double v = 0.0;
-                if (idx < KP * RESCORE_CH && r < n_rows && c0 + cc < dim) v = master[(size_t)sh_pos[r] * dim + c0 + cc];
-                pre[p][i] = v;
+                // clamped, never predicated (a load under a condition is waited for before the next one issues):
+                // rows >= n_rows are not walked and columns >= dim not stepped, so the duplicates are unused
+                int idx = tid + i * NTHREADS;
+                idx = idx < KP * RESCORE_CH ? idx : KP * RESCORE_CH - 1;
+                int r = idx / RESCORE_CH;
+                r = r < n_rows ? r : n_rows - 1;
+                uint32_t col = c0 + (uint32_t)(idx % RESCORE_CH);
+                col = col < dim ? col : dim - 1;
+                pre[p][i] = master[(size_t)sh_pos[r] * dim + col];
             }
-            qpre[p] = (tid < RESCORE_CH && c0 + tid < dim) ? q64[c0 + tid] : 0.0;
+            {
+                uint32_t col = c0 + (uint32_t)(tid % RESCORE_CH);
+                col = col < dim ? col : dim - 1;
+                qpre[p] = q64[col];
+            }
         }
 #pragma unroll
         for (int p = 0; p < PF; ++p) {

@@ -380,10 +380,14 @@ __global__ __launch_bounds__(256) void k_scan_bf16(const u32x4* __restrict__ sla
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             f32x4 v;
-            v.x = e0 + 4 * h + 0 < dim ? (float)q64[e0 + 4 * h + 0] : 0.0f;
-            v.y = e0 + 4 * h + 1 < dim ? (float)q64[e0 + 4 * h + 1] : 0.0f;
-            v.z = e0 + 4 * h + 2 < dim ? (float)q64[e0 + 4 * h + 2] : 0.0f;
-            v.w = e0 + 4 * h + 3 < dim ? (float)q64[e0 + 4 * h + 3] : 0.0f;
+            // clamped, never predicated (see load_q4 in kernels.hip)
+            const uint32_t b0 = e0 + 4 * h, last = dim - 1;
+            const double d0 = q64[b0 + 0 < dim ? b0 + 0 : last], d1 = q64[b0 + 1 < dim ? b0 + 1 : last];
+            const double d2 = q64[b0 + 2 < dim ? b0 + 2 : last], d3 = q64[b0 + 3 < dim ? b0 + 3 : last];
+            v.x = b0 + 0 < dim ? (float)d0 : 0.0f;
+            v.y = b0 + 1 < dim ? (float)d1 : 0.0f;
+            v.z = b0 + 2 < dim ? (float)d2 : 0.0f;
+            v.w = b0 + 3 < dim ? (float)d3 : 0.0f;
             qv[j][h] = v;
         }
     }
