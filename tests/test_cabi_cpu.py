@@ -79,3 +79,18 @@ def test_sources_do_not_reference_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "vl_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_header_is_valid_c99_and_a_plain_c_caller_links(tmp_path):
+    """The boundary is a C ABI: integration/c/example.c (gcc -std=c99 -pedantic -Wall -Werror) compiles against
+    include/vectorlite_amd.h and links against the built library.  (It runs in the GPU suite.)"""
+    import subprocess
+    from vectorlite_amd import _lib
+    exe = tmp_path / "example"
+    libdir = os.path.dirname(_lib.SO_PATH)
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "integration", "c", "example.c"), "-L", libdir, "-lvectorlite_amd",
+           "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined", "-lm", "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert exe.exists()
