@@ -230,7 +230,14 @@ __device__ __forceinline__ unsigned long long row_distance_f32(const HnswGraphVi
         }
     };
     uint32_t c = (uint32_t)half;
-    for (; c + 14 < ld4; c += 16) {  // 8 loads in flight per lane
+    for (; c + 30 < ld4; c += 32) {  // 16 loads in flight per lane: a 384-float row is 3 round trips, not 6
+        f32x4 x[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) x[t] = row[c + 2 * t];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) step(x[t], q4[c + 2 * t]);
+    }
+    for (; c + 14 < ld4; c += 16) {
         f32x4 x[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) x[t] = row[c + 2 * t];
