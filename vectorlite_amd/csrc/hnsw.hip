@@ -5,12 +5,12 @@
 // One WAVE per query / per inserted node:
 //   * a hop loads the <= 32 neighbour ids of the expanded node with one coalesced load and filters them
 //     through a per-wave visited-stamp array in HBM;
-//   * BUILD walks evaluate every surviving neighbour with the reference's callback: one lane walks one f64
-//     row in index order (separate multiply and add) -- the edge distances stored in the graph are exact;
-//   * QUERY walks navigate by f32 distances (two lanes per neighbour on the flat scan's f32 slab: half the
-//     bytes, half the serial length, 3x lower single-query latency) and then give every node of the final
-//     beam the exact f64 callback value -- the per-hop distance kernel of north_star -- from which the
-//     returned distances and scores are computed;
+//   * walks navigate by f32 distances (two lanes per neighbour on the flat scan's f32 slab: half the bytes
+//     and half the serial length of the f64 row; 3x lower single-query latency, 2x faster build);
+//   * a QUERY walk then gives every node of its final beam the reference's exact callback value -- one lane
+//     walks one f64 row in index order, separate multiply and add: the per-hop distance kernel of
+//     north_star -- from which the returned distances and scores are computed; the BUILD keeps f32-derived
+//     edge distances (used only to pick the farthest edge in the link phase);
 //   * the beam (result list + frontier in one) is a sorted list held one or two entries per lane,
 //     updated with ballot / DPP shifts like the flat scan's top-k list.
 #include "hnsw.hpp"
@@ -385,41 +385,46 @@ template <int METRIC, int S>
 __global__ __launch_bounds__(256) void k_hnsw_insert_search(HnswGraphView g, uint32_t first, uint32_t n, uint32_t efc,
                                                             uint32_t entry, int max_level, uint32_t flags)
 {
-    extern __shared__ double q_lds[];  // [4][2][dim]: the node's own row, then a candidate row
+    // The whole build works on f32 distances (row_distance_f32: two lanes per row of the f32 slab): walks,
+    // neighbour selection and the edge distances kept for the link phase.  Nothing of it reaches a caller --
+    // query walks re-evaluate their final beam with the reference's exact f64 callback.
+    extern __shared__ double q_lds[];  // per wave: [ld] f32 row of the node, then [ld] f32 row of a candidate
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
+    const int half = lane >> 5, nl = lane & 31;
     const uint32_t slot = blockIdx.x * 4 + wave;
     if (slot >= g.n_slots) return;
-    double* q = q_lds + (size_t)wave * 2 * g.dim;
-    double* cand = q + g.dim;
+    float* q32 = reinterpret_cast<float*>(q_lds) + (size_t)wave * 2 * g.ld;
+    float* cand32 = q32 + g.ld;
     uint32_t* stamps = g.stamps + (size_t)slot * g.cap;
     uint32_t epoch = g.epochs[slot];
+    uint32_t evals = 0;
 
     for (uint32_t i = slot; i < n; i += gridDim.x * 4) {
         const uint32_t p = first + i;
         const int lp = g.level[p];
-        for (uint32_t c = lane; c < g.dim; c += 64) q[c] = g.master[(size_t)p * g.dim + c];
+        for (uint32_t c = lane; c < g.ld; c += 64) q32[c] = g.slab[(size_t)p * g.ld + c];
+        const float q_inv = g.inv_norm[p];
         __builtin_amdgcn_wave_barrier();
         BeamList<S> L;
         L.init();
         epoch += 1;
         {
-            unsigned long long d0 = 0;
-            if (lane == 0) d0 = row_distance<METRIC>(g.master + (size_t)entry * g.dim, q, g.dim);
+            unsigned long long d0 = row_distance_f32<METRIC>(g, entry, q32, q_inv, half);
             d0 = read_lane(d0, 0);
             L.insert(d0, entry, 1);
             if (lane == 0) stamps[entry] = epoch;
         }
         for (int layer = max_level; layer > lp; --layer) {  // greedy descent above the node's own level
-            beam_layer<METRIC, S>(g, q, layer, stamps, epoch, L, 1);
+            beam_layer_f32<METRIC, S>(g, q32, q_inv, layer, stamps, epoch, L, 1, &evals);
             next_layer(L, stamps, epoch);
         }
         for (int layer = lp < max_level ? lp : max_level; layer >= 0; --layer) {
-            beam_layer<METRIC, S>(g, q, layer, stamps, epoch, L, (int)efc);
+            beam_layer_f32<METRIC, S>(g, q32, q_inv, layer, stamps, epoch, L, (int)efc, &evals);
             // neighbour selection (the HNSW diversity heuristic): walk the beam from the closest
             // candidate outwards and keep a candidate only if it is closer to p than to every
             // neighbour kept so far -- this is what gives the graph its long edges.  Lane j holds
-            // kept neighbour j and checks candidates against it in parallel (one row walk per lane).
+            // kept neighbour j; lanes j and j + 32 measure the candidate against it together.
             const uint32_t cap = layer == 0 ? g.m0 : g.m;
             uint32_t* nb;
             unsigned long long* nd;
@@ -448,10 +453,15 @@ __global__ __launch_bounds__(256) void k_hnsw_insert_search(HnswGraphView g, uin
                 cv &= ~EXPANDED;
                 bool bad = false;
                 if (nsel > 0 && (flags & 1u)) {
-                    for (uint32_t c = lane; c < g.dim; c += 64) cand[c] = g.master[(size_t)cv * g.dim + c];
+                    for (uint32_t c = lane; c < g.ld; c += 64) cand32[c] = g.slab[(size_t)cv * g.ld + c];
+                    const float c_inv = g.inv_norm[cv];
                     __builtin_amdgcn_wave_barrier();
-                    if ((uint32_t)lane < nsel)
-                        bad = row_distance<METRIC>(g.master + (size_t)selv * g.dim, cand, g.dim) < dc;
+                    for (uint32_t base = 0; base < nsel; base += 32) {  // kept neighbours in rounds of 32 lane pairs
+                        const uint32_t kj = base + (uint32_t)nl;
+                        const uint32_t kn = (uint32_t)__shfl((int)selv, (int)(kj & 63u));
+                        if (kj < nsel) bad = bad || row_distance_f32<METRIC>(g, kn, cand32, c_inv, half) < dc;
+                    }
+                    __builtin_amdgcn_wave_barrier();
                 }
                 if (__ballot(bad) == 0ull) {
                     if ((uint32_t)lane == nsel) {
@@ -620,7 +630,7 @@ hipError_t launch_hnsw_insert_search(hipStream_t s, int metric, const HnswGraphV
     if (n == 0) return hipSuccess;
     if (ef_construction == 0 || ef_construction > (uint32_t)HNSW_MAX_EF || g.m0 > 64 || g.m > 64)
         return hipErrorInvalidValue;
-    const size_t lds = (size_t)8 * g.dim * sizeof(double);
+    const size_t lds = (size_t)4 * 2 * g.ld * sizeof(float);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     const int grid = grid_for(g, n);
     return dispatch_metric(metric, [&](auto M) -> hipError_t {

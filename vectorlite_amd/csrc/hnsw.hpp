@@ -1,8 +1,9 @@
 // hnsw.hpp -- device graph walk behind the reference's HNSWIndex (src/index/hnsw.rs).
 //
 // What the reference owns and this file reproduces exactly: the four `Metric::distance`
-// callbacks -> u64 (src/index/hnsw.rs:113-174), evaluated per hop on the GPU in the reference's
-// f64 operation order (device_common.hpp: Acc64 + hnsw_quantise).
+// callbacks -> u64 (src/index/hnsw.rs:113-174), evaluated on the GPU in the reference's f64
+// operation order (device_common.hpp: Acc64 + hnsw_quantise) for every node a query returns
+// and through vl_index_hnsw_distances; navigation inside the walks uses f32 distances.
 // What the reference delegates to crate `hnsw 0.11.0` (source not vendored, Cargo.lock:1111-1123):
 // the graph build and walk.  This is OUR OWN traversal (standard HNSW: greedy descent through the
 // upper layers, beam search of width ef on layer 0; M = 16, M0 = 32 like src/index/hnsw.rs:95-109).
