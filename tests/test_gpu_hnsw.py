@@ -249,3 +249,26 @@ def test_coalesced_concurrent_hnsw_searches_match_lone_searches(V):
     assert errors == []
     batches, queries = idx.coalesce_stats()
     assert queries == nq and batches < queries
+
+
+@pytest.mark.parametrize("dim", [1536, 3072])
+def test_large_embedding_dimensions(V, O, dim):
+    """1536 / 3072-dimensional rows (the walk keeps the query in LDS: more than the 64 KB default per workgroup)."""
+    rng = np.random.default_rng(dim)
+    n = 3000
+    z = rng.standard_normal((n, 12)) @ rng.standard_normal((12, dim)) + 0.05 * rng.standard_normal((n, dim))
+    idx = V.HNSWIndex(dim, V.SimilarityMetric.Cosine)
+    idx.add_rows(np.arange(n, dtype=np.uint64), z)
+    flat = V.FlatIndex(dim)
+    flat.add_rows(np.arange(n, dtype=np.uint64), z, validate=False)
+    Q = z[rng.integers(0, n, 20)] + 0.01 * rng.standard_normal((20, dim))
+    hi, hs, hn = idx.search_batch(Q, 10, V.SimilarityMetric.Cosine, ef=64)
+    fi, fs, fn = flat.search_batch(Q, 10, V.SimilarityMetric.Cosine)
+    rec = np.mean([len(set(hi[i].tolist()) & set(fi[i].tolist())) / 10.0 for i in range(20)])
+    assert rec >= 0.9, rec
+    for i in range(3):  # returned scores are the reference conversion of the exact u64 distance
+        for j in range(int(hn[i])):
+            d = O.hnsw_distance(0, Q[i], z[int(hi[i, j])])
+            assert hs[i, j] == O.hnsw_score(d, 0)
+    with pytest.raises(Exception):
+        V.HNSWIndex(3073, V.SimilarityMetric.Cosine)

@@ -15,6 +15,7 @@
 //     updated with ballot / DPP shifts like the flat scan's top-k list.
 #include "hnsw.hpp"
 
+#include <mutex>
 #include <type_traits>
 
 #include "device_common.hpp"
@@ -595,6 +596,26 @@ hipError_t dispatch_metric(int metric, F&& f)
     }
 }
 
+// Dynamic LDS above the 64 KB default needs the per-kernel attribute (gfx950 has 160 KB per CU); raised once
+// per kernel to the ceiling this file ever asks for.
+constexpr size_t HNSW_LDS_MAX = 152 * 1024;
+template <typename K>
+hipError_t allow_big_lds(K kernel, size_t lds)
+{
+    if (lds <= 64 * 1024) return hipSuccess;
+    // keyed by the kernel's address (all metric instantiations share one function-pointer TYPE)
+    static std::mutex mu;
+    static const void* seen[64];
+    static int n_seen = 0;
+    const void* key = reinterpret_cast<const void*>(kernel);
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < n_seen; ++i)
+        if (seen[i] == key) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HNSW_LDS_MAX);
+    if (e == hipSuccess && n_seen < 64) seen[n_seen++] = key;
+    return e;
+}
+
 int grid_for(const HnswGraphView& g, uint32_t work)
 {
     uint32_t waves = work < g.n_slots ? work : g.n_slots;
@@ -610,17 +631,17 @@ hipError_t launch_hnsw_search(hipStream_t s, int metric, const HnswGraphView& g,
     if (nq == 0) return hipSuccess;
     if (ef == 0 || ef > (uint32_t)HNSW_MAX_EF || g.m0 > 64 || g.m > 64) return hipErrorInvalidValue;
     const size_t lds = (size_t)4 * ((((size_t)g.ld / 2 + g.dim + 1) & ~(size_t)1)) * sizeof(double);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    if (lds > HNSW_LDS_MAX) return hipErrorInvalidValue;
     const int grid = grid_for(g, nq);
     return dispatch_metric(metric, [&](auto M) -> hipError_t {
         constexpr int MM = decltype(M)::value;
-        if (ef <= 64)
-            hipLaunchKernelGGL((k_hnsw_search<MM, 1>), dim3(grid), dim3(256), lds, s, g, queries, nq, ef, entry,
-                               max_level, out);
-        else
-            hipLaunchKernelGGL((k_hnsw_search<MM, 2>), dim3(grid), dim3(256), lds, s, g, queries, nq, ef, entry,
-                               max_level, out);
-        return hipGetLastError();
+        auto launch = [&](auto kern) -> hipError_t {
+            const hipError_t e = allow_big_lds(kern, lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, g, queries, nq, ef, entry, max_level, out);
+            return hipGetLastError();
+        };
+        return ef <= 64 ? launch(k_hnsw_search<MM, 1>) : launch(k_hnsw_search<MM, 2>);
     });
 }
 
@@ -631,17 +652,17 @@ hipError_t launch_hnsw_insert_search(hipStream_t s, int metric, const HnswGraphV
     if (ef_construction == 0 || ef_construction > (uint32_t)HNSW_MAX_EF || g.m0 > 64 || g.m > 64)
         return hipErrorInvalidValue;
     const size_t lds = (size_t)4 * 2 * g.ld * sizeof(float);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    if (lds > HNSW_LDS_MAX) return hipErrorInvalidValue;
     const int grid = grid_for(g, n);
     return dispatch_metric(metric, [&](auto M) -> hipError_t {
         constexpr int MM = decltype(M)::value;
-        if (ef_construction <= 64)
-            hipLaunchKernelGGL((k_hnsw_insert_search<MM, 1>), dim3(grid), dim3(256), lds, s, g, first, n,
-                               ef_construction, entry, max_level, flags);
-        else
-            hipLaunchKernelGGL((k_hnsw_insert_search<MM, 2>), dim3(grid), dim3(256), lds, s, g, first, n,
-                               ef_construction, entry, max_level, flags);
-        return hipGetLastError();
+        auto launch = [&](auto kern) -> hipError_t {
+            const hipError_t e = allow_big_lds(kern, lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, g, first, n, ef_construction, entry, max_level, flags);
+            return hipGetLastError();
+        };
+        return ef_construction <= 64 ? launch(k_hnsw_insert_search<MM, 1>) : launch(k_hnsw_insert_search<MM, 2>);
     });
 }
 

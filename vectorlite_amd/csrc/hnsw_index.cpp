@@ -93,8 +93,8 @@ int HnswIndex::create(uint64_t dim, int metric, const HnswParams& p, int device,
         return ERR_INVALID_ARG;
     }
     if (p.m == 0 || p.m > 64 || p.m0 == 0 || p.m0 > 64 || p.ef_construction == 0 ||
-        p.ef_construction > (uint32_t)HNSW_MAX_EF || dim * 8 * sizeof(double) > 64 * 1024) {
-        set_last_error("HNSW parameters out of range (M, M0 <= 64; ef_construction <= 128; dim <= 1024)");
+        p.ef_construction > (uint32_t)HNSW_MAX_EF || dim > 3072) {  // the walk keeps the query in LDS: 48 B per dimension per workgroup
+        set_last_error("HNSW parameters out of range (M, M0 <= 64; ef_construction <= 128; dim <= 3072)");
         return ERR_INVALID_ARG;
     }
     std::unique_ptr<HnswIndex> h(new HnswIndex(dim, metric, p, device));
