@@ -272,3 +272,28 @@ def test_large_embedding_dimensions(V, O, dim):
             assert hs[i, j] == O.hnsw_score(d, 0)
     with pytest.raises(Exception):
         V.HNSWIndex(3073, V.SimilarityMetric.Cosine)
+
+
+def test_k_above_the_beam_limit_is_answered_exactly(V, O):
+    """ef = min(k, len) > 128 does not fit the walk kernel's beam: the row store's exact scan answers, in
+    Metric::distance order, with the walk's post-processing (tombstones dropped, scores converted, stable sort)."""
+    rng = np.random.default_rng(77)
+    n, dim = 1500, 24
+    z = rng.standard_normal((n, dim))
+    m = V.SimilarityMetric.Euclidean
+    idx = V.HNSWIndex(dim, m)
+    ids = np.arange(n, dtype=np.uint64) + 500
+    idx.add_rows(ids, z)
+    for dead in (3, 77, 600):
+        idx.delete(int(ids[dead]))
+    q = z[10] + 0.05
+    for k in (129, 400, 5000):
+        res = idx.search(q, k, m)
+        live = [i for i in range(n) if i not in (3, 77, 600)]
+        d = {i: O.hnsw_distance(1, q, z[i]) for i in live}
+        want_n = min(k, len(live))
+        assert len(res) == want_n
+        got_d = [d[int(r.id) - 500] for r in res]
+        assert got_d == sorted(got_d)                                   # nearest first
+        assert max(got_d) <= sorted(d.values())[want_n - 1]              # exactly the want_n nearest (ties aside)
+        assert all(r.score == O.hnsw_score(d[int(r.id) - 500], 1) for r in res)

@@ -429,6 +429,42 @@ int HnswIndex::ensure_search_scratch(uint64_t nq, uint32_t ef) const
     return OK;
 }
 
+int HnswIndex::search_exact_fallback(const double* query, uint64_t k, uint64_t* out_ids, double* out_scores,
+                                     uint64_t* out_n) const
+{
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    *out_n = 0;
+    if (live_count_ == 0) return OK;
+    // every tombstoned node could sit in front of a live one: ask for that many more
+    const uint64_t want = std::min<uint64_t>(n_nodes_, k + (n_nodes_ - live_count_));
+    std::vector<uint64_t> pos(want);
+    std::vector<double> flat_scores(want);
+    uint64_t got = 0;
+    // the flat metric score is a decreasing function of Metric::distance's f64 value for all four metrics
+    VL_TRY(store_->search(query, dim_, want, metric_, pos.data(), nullptr, flat_scores.data(), &got));
+    std::vector<uint64_t> dist(got);
+    VL_TRY(store_->hnsw_distances(query, dim_, metric_, pos.data(), got, dist.data()));
+    struct Res {
+        uint64_t id;
+        double score;
+    };
+    std::vector<Res> res;
+    stat_queries_.fetch_add(1, std::memory_order_relaxed);
+    stat_evals_.fetch_add(n_nodes_ + got, std::memory_order_relaxed);
+    const uint64_t max_candidates = std::min<uint64_t>(k, live_count_);
+    for (uint64_t i = 0; i < got && res.size() < max_candidates; ++i) {
+        if (pos[i] >= n_nodes_ || !live_[pos[i]]) continue;
+        res.push_back({node_id_[pos[i]], hnsw_score(dist[i], metric_)});
+    }
+    std::stable_sort(res.begin(), res.end(), [](const Res& a, const Res& b) { return a.score > b.score; });  // :493
+    for (uint64_t i = 0; i < res.size(); ++i) {
+        out_ids[i] = res[i].id;
+        out_scores[i] = res[i].score;
+    }
+    *out_n = res.size();
+    return OK;
+}
+
 namespace {
 // Rust `f64 as u64` (truncation toward zero, saturating, NaN -> 0) of the f64 whose bits are `key`
 uint64_t rust_as_u64_host(uint64_t key)
@@ -510,8 +546,13 @@ int HnswIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_len, 
     uint64_t ef_walk = std::max<uint64_t>(max_candidates, ef);
     if (ef_walk > (uint64_t)HNSW_MAX_EF) {
         if (max_candidates > (uint64_t)HNSW_MAX_EF) {
-            set_last_error("HNSW search supports k <= 128 in this build");
-            return ERR_INVALID_ARG;
+            // A beam wider than the walk kernel holds (ef = min(k, len) > 128): answer from the row store with
+            // the exact scan instead -- the true nearest neighbours in Metric::distance order, i.e. what a perfect
+            // walk would return, post-processed exactly like a walk's beam below.
+            lk.unlock();
+            for (uint64_t qi = 0; qi < nq; ++qi)
+                VL_TRY(search_exact_fallback(queries + qi * dim_, k, out_ids + qi * k, out_scores + qi * k, out_n + qi));
+            return OK;
         }
         ef_walk = HNSW_MAX_EF;
     }

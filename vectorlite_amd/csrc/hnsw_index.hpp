@@ -75,6 +75,7 @@ private:
     int ensure_graph(uint64_t nodes, uint64_t upper_slots);
     HnswGraphView view() const;
     int ensure_search_scratch(uint64_t nq, uint32_t ef) const;
+    int search_exact_fallback(const double* query, uint64_t k, uint64_t* out_ids, double* out_scores, uint64_t* out_n) const;
 
     const uint64_t dim_;
     const int metric_;
