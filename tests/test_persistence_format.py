@@ -231,3 +231,55 @@ def test_native_loader_builds_the_same_index_as_bulk_add(tmp_path):
     p.write_text(json.dumps(ragged))
     with pytest.raises(P.PersistenceError, match="Vector dimension mismatch: expected 3, got 2"):
         P.load_collection_from_file(str(p))
+
+
+def test_native_reader_survives_mutated_files(tmp_path):
+    """1500 seeded mutations (byte flips, cuts, duplicated spans, stray quotes / brackets / escapes, truncations)
+    of valid Flat and HNSW documents: the reader either accepts the file or reports a PersistenceError --
+    it never crashes, and whatever it accepts can be read back completely."""
+    import random
+    from vectorlite_amd import persistence as P
+    doc = _doc()
+    doc["index"]["Flat"]["data"][0]["text"] = "a \" b \\ é"
+    doc["index"]["Flat"]["data"][1]["metadata"] = {"k": [1, {"z": "]}"}]}
+    hn = json.loads(json.dumps(_doc()))
+    hn["index"] = {"HNSW": {"dim": 2, "metric": "Cosine", "id_to_index": {}, "index_to_id": {},
+                            "metadata": {"5": {"text": "t", "metadata": None}},
+                            "vector_values": {"5": [1.0, 2.0], "6": [0.5, -1]}}}
+    bases = [json.dumps(doc, indent=2).encode(), json.dumps(doc, separators=(",", ":")).encode(), json.dumps(hn, indent=1).encode()]
+    rnd = random.Random(7)
+    path = str(tmp_path / "f.vlc")
+    accepted = 0
+    for _ in range(1500):
+        b = bytearray(rnd.choice(bases))
+        for _ in range(rnd.randint(1, 4)):
+            op = rnd.randint(0, 4)
+            if op == 0:
+                b[rnd.randrange(len(b))] = rnd.randrange(256)
+            elif op == 1 and len(b) > 1:
+                del b[rnd.randrange(len(b)):rnd.randrange(len(b)) or None]
+            elif op == 2:
+                i = rnd.randrange(len(b) + 1)
+                b[i:i] = rnd.choice([b'"', b"\\", b"[", b"]", b"{", b"}", b",", b":", b"\\u12", b"1e999", b"-", b"\x00", b'"\\'])
+            elif op == 3 and len(b) > 10:
+                i = rnd.randrange(len(b) - 5)
+                j = i + rnd.randint(1, 5)
+                b[i:j] = b[i:j] * rnd.randint(2, 4)
+            else:
+                b = b[: rnd.randrange(len(b) + 1)]
+            if not b:
+                b = bytearray(b" ")
+        with open(path, "wb") as f:
+            f.write(bytes(b))
+        try:
+            d = P.VlcDocument(path)
+        except (P.PersistenceError, UnicodeDecodeError):
+            continue
+        try:
+            d.values()
+            d.side_data(True)
+        except (P.PersistenceError, ValueError, UnicodeDecodeError):
+            pass
+        d.close()
+        accepted += 1
+    assert 0 < accepted < 1500
