@@ -814,3 +814,67 @@ def test_exact_select_rounds_for_k_above_64(V, O):
             assert V.last_path() == (V.PATH_EXACT_SELECT if k <= 128 else V.PATH_EXACT_SORT)
     assert_same(V, gpu.search_arrays(q, 1000, 0), ref.search(q, 1000, 0), "k=1000")
     assert V.last_path() == V.PATH_EXACT_SORT
+
+
+def test_concurrent_writers_and_coalesced_readers_do_not_deadlock_or_corrupt(V, O):
+    """Readers (coalesced and not) run against a writer that adds, deletes and bulk-adds (RwLock::write in the
+    reference, src/client.rs:333,383).  Every answer must be a valid answer for SOME state the index went through:
+    checked here through invariants (sorted scores, ids that existed, no duplicates), then exactly once quiescent."""
+    import threading
+    rng = np.random.default_rng(99)
+    dim, n0 = 64, 20000
+    rows = unit_rows(rng, n0, dim)
+    ids = np.arange(n0, dtype=np.uint64)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows, validate=False)
+    gpu.set_coalescing(32, 50)
+    extra = unit_rows(rng, 400, dim)
+    stop = threading.Event()
+    errors = []
+    known = set(range(n0 + 400))
+
+    def reader(t):
+        r = np.random.default_rng(1000 + t)
+        try:
+            while not stop.is_set():
+                q = unit_rows(r, 1, dim)[0]
+                k = int(r.choice([1, 10, 48]))
+                gi, gs = gpu.search_arrays(q, k, int(r.integers(0, 4)))
+                if len(gi) != k or len(set(gi.tolist())) != k or not set(gi.tolist()) <= known:
+                    errors.append(("ids", t, gi.tolist()))
+                if any(gs[i] < gs[i + 1] for i in range(len(gs) - 1)):
+                    errors.append(("order", t))
+        except Exception as e:  # pragma: no cover
+            errors.append((t, repr(e)))
+
+    def writer():
+        try:
+            for j in range(200):
+                gpu.add(V.Vector(n0 + j, extra[j]))
+                if j % 3 == 0:
+                    gpu.delete(int(j * 7))
+            gpu.add_rows(np.arange(n0 + 200, n0 + 400, dtype=np.uint64), extra[200:])
+        except Exception as e:  # pragma: no cover
+            errors.append(("writer", repr(e)))
+
+    readers = [threading.Thread(target=reader, args=(t,)) for t in range(8)]
+    [t.start() for t in readers]
+    w = threading.Thread(target=writer)
+    w.start()
+    w.join(timeout=120)
+    stop.set()
+    [t.join(timeout=60) for t in readers]
+    assert not w.is_alive() and not any(t.is_alive() for t in readers), "deadlock"
+    assert errors == []
+    # quiescent: exact comparison with an oracle that received the same writes
+    ref = O.FlatOracle(dim, ids, rows)
+    for j in range(200):
+        ref.add(n0 + j, extra[j])
+        if j % 3 == 0:
+            ref.delete(int(j * 7))
+    for j in range(200, 400):
+        ref.add(n0 + j, extra[j])
+    assert len(gpu) == len(ref)
+    q = unit_rows(rng, 1, dim)[0]
+    for m in range(4):
+        assert_same(V, gpu.search_arrays(q, 10, m), ref.search(q, 10, m), m)
