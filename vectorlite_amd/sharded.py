@@ -95,12 +95,10 @@ class ShardedFlatIndex:
         if len(self.local) != 0 and k != 0:
             if hasattr(self.local, "search_batch_positions"):  # GPU shard: queries share slab passes
                 bpos, bids, bsc, bn = self.local.search_batch_positions(Q, k, metric)
-                for qi in range(nq):
-                    c = int(bn[qi])
-                    packed[qi, :c, 0] = np.ascontiguousarray(bsc[qi, :c]).view(np.int64)
-                    packed[qi, :c, 1] = bpos[qi, :c].astype(np.int64) + self.offset
-                    packed[qi, :c, 2] = np.ascontiguousarray(bids[qi, :c]).view(np.int64)
-                    packed[qi, kk, 0] = c
+                packed[:, : int(k), 0] = np.ascontiguousarray(bsc, dtype=np.float64).view(np.int64)
+                packed[:, : int(k), 1] = bpos.astype(np.int64) + self.offset
+                packed[:, : int(k), 2] = np.ascontiguousarray(bids, dtype=np.uint64).view(np.int64)
+                packed[:, kk, 0] = bn.astype(np.int64)
             else:
                 for qi in range(nq):
                     pos, ids, scores = self.local.search_positions(Q[qi], k, metric)
@@ -110,20 +108,22 @@ class ShardedFlatIndex:
                     packed[qi, :c, 2] = np.asarray(ids, dtype=np.uint64).view(np.int64)
                     packed[qi, kk, 0] = c
         gathered = self._all_gather(packed.reshape(-1)).reshape(self.world, nq, kk + 1, 3)
-        out_ids = np.zeros((nq, kk), dtype=np.uint64)
-        out_scores = np.zeros((nq, kk), dtype=np.float64)
-        out_n = np.zeros(nq, dtype=np.uint64)
-        for qi in range(nq):
-            g = gathered[:, qi]
-            counts = g[:, kk, 0]
-            scores = g[:, :kk, 0].copy().view(np.float64)
-            gpos = g[:, :kk, 1]
-            ids = g[:, :kk, 2].copy().view(np.uint64)
-            mi, ms, _ = merge_shard_results(scores, gpos, ids, counts, int(k))
-            out_ids[qi, : len(mi)] = mi
-            out_scores[qi, : len(ms)] = ms
-            out_n[qi] = len(mi)
-        return out_ids[:, : int(k)], out_scores[:, : int(k)], out_n
+        # merge for all queries at once: [nq, world * kk] candidates, entries beyond a shard's count pushed
+        # behind everything, then the reference's order -- score descending, global position ascending
+        counts = gathered[:, :, kk, 0]                                             # [world, nq]
+        valid = np.arange(kk)[None, None, :] < counts[:, :, None]                  # [world, nq, kk]
+        sc = np.ascontiguousarray(gathered[:, :, :kk, 0]).view(np.float64)
+        sc = np.where(valid, sc, -np.inf).transpose(1, 0, 2).reshape(nq, -1)
+        gp = np.where(valid, gathered[:, :, :kk, 1], np.iinfo(np.int64).max).transpose(1, 0, 2).reshape(nq, -1)
+        gi = gathered[:, :, :kk, 2].transpose(1, 0, 2).reshape(nq, -1)
+        order = np.lexsort((gp, -sc), axis=-1)[:, :kk]
+        total = np.minimum(counts.sum(axis=0), int(k)).astype(np.uint64)           # [nq]
+        out_scores = np.take_along_axis(sc, order, axis=1)
+        out_ids = np.ascontiguousarray(np.take_along_axis(gi, order, axis=1)).view(np.uint64)
+        live = np.arange(kk)[None, :] < total[:, None]
+        out_scores = np.where(live, out_scores, 0.0)
+        out_ids = np.where(live, out_ids, np.uint64(0))
+        return out_ids[:, : int(k)], out_scores[:, : int(k)], total
 
     def search(self, query, k: int, metric: int = 0):
         ids, scores, n = self.search_batch(np.asarray(query, dtype=np.float64)[None, :], k, metric)
