@@ -16,8 +16,9 @@ constexpr int MFMA_MAX_BATCH = 1024;   // queries per launch sequence (scratch i
 // Fewer rows than this (MFMA_GROUPS tiles of 32) leave the sampling pass with fewer than 64 groups: no
 // threshold, every score a candidate, guaranteed buffer overflow -- such indexes take the f32 batch path.
 constexpr uint64_t MFMA_MIN_ROWS = (uint64_t)MFMA_GROUPS * 32;
-constexpr int MFMA_MIN_BATCH = 8;      // below this the f32 batch path is used (measured: one bf16 pass of
-                                       // 1.9 ms answers 8..256 queries; the f32 path needs 2.7 ms per 8)
+constexpr int MFMA_MIN_BATCH = 2;      // measured at N = 10 M x 384: one bf16 pass answers 2..256 queries in 1.9-2.0 ms,
+                                       // the f32 batch kernel needs 2.7-2.9 ms per pass of up to 8 (it stays for Manhattan,
+                                       // row lengths without an MFMA shape, and as the fallback)
 
 // bf16 slab row stride in elements: dim rounded up to the MFMA K step (16)
 inline uint32_t mfma_ldb(uint32_t dim) { return (dim + 15u) & ~15u; }
