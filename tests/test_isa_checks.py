@@ -79,5 +79,5 @@ def test_mfma_scan_default_shapes_do_not_spill():
         seen += 1
         scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1))
         assert scratch <= 128, (name, scratch)
-        assert "v_mfma_f32_32x32x16_bf16" in asm
+        assert "v_mfma_f32_16x16x32_bf16" in asm
     assert seen >= 24

@@ -2,8 +2,8 @@
 //
 // No reference counterpart (the reference has no batch search, src/lib.rs:224-245).  With hundreds of
 // queries per slab pass the scan stops being HBM-bound, so scores[row, query] are
-// computed on the matrix cores: v_mfma_f32_32x32x16_bf16, rows as the A operand (streamed through
-// LDS, one contiguous 32-row tile at a time), 32 queries per wave as the B operand held in registers
+// computed on the matrix cores: v_mfma_f32_16x16x32_bf16 (2 x 2 blocks of 16 per wave), rows as the A operand
+// (streamed through LDS, one contiguous 32-row tile at a time), 32 queries per wave as the B operand held in registers
 // for the whole launch (256 queries per 8-wave workgroup share every row tile).
 //
 // bf16 scores are only a CANDIDATE FILTER.  The Q x N score matrix is never written:
@@ -54,7 +54,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
 {
     constexpr int LDB = KSTEPS * 16;            // bf16 elements per row
     constexpr int ROW_BYTES = LDB * 2;
-    constexpr int LDS_ROW = ROW_BYTES + 16;     // +16 B: 32 rows land on 16 distinct 4-bank slots
+    // +32 B: a 16x16x32 A fragment is read as row (lane & 15) + 16 rb, 16 bytes at k-group (lane >> 4); with two
+    // 16-byte slots of padding per row the 16 lanes of every ds_read_b128 group hit 16 distinct slots
+    constexpr int LDS_ROW = ROW_BYTES + 32;
     constexpr int CHUNKS = MF_ROWS * ROW_BYTES / 16;  // 16-byte pieces per tile
     constexpr int NT = NWAVES * 64;                   // threads per workgroup
     constexpr int MF_QPB = NWAVES * 32 * QT;          // queries per workgroup: QT 32-column MFMA tiles per wave
@@ -80,19 +82,26 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int col = lane & 31, half = lane >> 5;
-    // this lane's queries (B columns): one per 32-column tile
-    uint32_t q[QT];
-    bool q_valid[QT];
-    bf16x8 bfrag[QT][KSTEPS];
+    // v_mfma_f32_16x16x32_bf16 (holds a higher clock than the 32x32x16 form on this chip: 1.76 vs 1.27-1.45 PF in
+    // the bare fragment loop, tools/micro/mfma_loop.hip).  A wave still owns 32 rows x 32 queries per QT tile,
+    // as 2 row blocks x 2 query blocks of 16: lane = (c16, kg) holds row/query c16 of its block and the 8 values
+    // k = 32 s + 8 kg .. + 7 of K step s.
+    const int c16 = lane & 15, kg = lane >> 4;
+    constexpr int KS32 = KSTEPS / 2;  // K = 32 per MFMA
+    static_assert(KSTEPS % 2 == 0, "whole 32-deep K steps");
+    uint32_t q[QT][2];
+    bool q_valid[QT][2];
+    bf16x8 bfrag[QT][2][KS32];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        q[qt] = blockIdx.y * MF_QPB + (wave * QT + qt) * 32 + col;
-        q_valid[qt] = q[qt] < nq;
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s)
-            bfrag[qt][s] = *reinterpret_cast<const bf16x8*>(q16 + (size_t)q[qt] * LDB + 16 * s + 8 * half);
-    }
+        for (int qb = 0; qb < 2; ++qb) {
+            q[qt][qb] = blockIdx.y * MF_QPB + (wave * QT + qt) * 32 + qb * 16 + c16;
+            q_valid[qt][qb] = q[qt][qb] < nq;
+#pragma unroll
+            for (int s = 0; s < KS32; ++s)
+                bfrag[qt][qb][s] = *reinterpret_cast<const bf16x8*>(q16 + (size_t)q[qt][qb] * LDB + 32 * s + 8 * kg);
+        }
 
     // tile schedule: workgroup x takes tiles x, x + gridDim.x, ... in both modes, so neighbouring
     // workgroups stream neighbouring tiles.  In MODE 0 that residue class is the workgroup's "group":
@@ -100,13 +109,15 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
     uint32_t t = tile_begin + blockIdx.x;  // MODE 1 runs in stages over [tile_begin, n_tiles)
     const uint32_t t_end = n_tiles, t_step = gridDim.x;
 
-    float thr_q[QT], run_max[QT];
+    float thr_q[QT][2], run_max[QT][2];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        thr_q[qt] = INFINITY;  // padding queries never pass
-        if (MODE == 1 && q_valid[qt]) thr_q[qt] = thr[q[qt]];
-        run_max[qt] = -INFINITY;
-    }
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            thr_q[qt][qb] = INFINITY;  // padding queries never pass
+            if (MODE == 1 && q_valid[qt][qb]) thr_q[qt][qb] = thr[q[qt][qb]];
+            run_max[qt][qb] = -INFINITY;
+        }
 
     // Register prefetch ring: DEPTH tiles are in flight per workgroup.  One workgroup per CU leaves
     // only the loop itself to hide the ~2 us HBM latency, and one tile's MFMAs cover a fraction of it.
@@ -152,8 +163,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
         if (MODE == 0) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt)
-                if (q_valid[qt] && half == 0 && blockIdx.x < n_groups)
-                    gmax[(size_t)q[qt] * n_groups + blockIdx.x] = enc_f(-INFINITY);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+                    if (q_valid[qt][qb] && kg == 0 && blockIdx.x < n_groups)
+                        gmax[(size_t)q[qt][qb] * n_groups + blockIdx.x] = enc_f(-INFINITY);
         }
         return;
     }
@@ -209,101 +222,112 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
                 issue_loads(nt < t_end ? nt : t_last, stage[j], stage_inv[j], stage_sqn[j]);
             }
 
-            f32x16 acc[QT];
+            f32x4 acc[QT][2][2];  // [row block][query block]: rows 16 rb + 4 kg + reg, query 16 qb + c16
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[qt][r] = 0.0f;
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) acc[qt][rb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
             // A fragments are read from LDS one GROUP ahead of the MFMAs that consume them (left alone
             // the compiler reuses one register quad and every MFMA waits out an LDS round trip); each
-            // fragment feeds QT MFMAs.
-            const unsigned char* arow = &a_lds[buf][col * LDS_ROW + half * 16];
-            constexpr int GS = 4;
-            constexpr int NG = KSTEPS / GS;
-            static_assert(KSTEPS % GS == 0, "K steps come in whole groups");
-            bf16x8 afrag[2][GS];
+            // fragment feeds 2 QT MFMAs.
+            const unsigned char* arow = &a_lds[buf][c16 * LDS_ROW + kg * 16];
+            constexpr int GS = 2;            // K = 32 steps per group: 4 fragment reads, 8 QT MFMAs of 16 cycles
+            constexpr int NG = KS32 / GS;
+            static_assert(KS32 % GS == 0, "K steps come in whole groups");
+            bf16x8 afrag[2][GS][2];
 #pragma unroll
-            for (int jj = 0; jj < GS; ++jj) afrag[0][jj] = *reinterpret_cast<const bf16x8*>(arow + jj * 32);
+            for (int jj = 0; jj < GS; ++jj)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+                    afrag[0][jj][rb] = *reinterpret_cast<const bf16x8*>(arow + rb * 16 * LDS_ROW + jj * 64);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 if (g + 1 < NG) {
 #pragma unroll
                     for (int jj = 0; jj < GS; ++jj)
-                        afrag[(g + 1) & 1][jj] = *reinterpret_cast<const bf16x8*>(arow + ((g + 1) * GS + jj) * 32);
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb)
+                            afrag[(g + 1) & 1][jj][rb] =
+                                *reinterpret_cast<const bf16x8*>(arow + rb * 16 * LDS_ROW + ((g + 1) * GS + jj) * 64);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int jj = 0; jj < GS; ++jj)
 #pragma unroll
-                    for (int qt = 0; qt < QT; ++qt)
-                        acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[g & 1][jj], bfrag[qt][g * GS + jj],
-                                                                          acc[qt], 0, 0, 0);
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                            for (int qb = 0; qb < 2; ++qb)
+                                acc[qt][rb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    afrag[g & 1][jj][rb], bfrag[qt][qb][g * GS + jj], acc[qt][rb][qb], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // C layout: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5):
-            // registers 4g..4g+3 are the four consecutive rows 8g + 4*half + {0..3}.
-            // Epilogue on the common path = 16 multiplies, a max tree and ONE compare against the
-            // query's threshold; the per-row work only runs for the rare tile that holds a candidate.
+            // C layout of a 16x16 block: column = lane & 15 (query), row = 4 (lane >> 4) + reg.
+            // Epilogue on the common path = the key arithmetic, a max tree and ONE compare per query
+            // against its threshold; the per-row work only runs for the rare tile that holds a candidate.
             const uint32_t row0 = tile * MF_ROWS;
-            f32x4 aux[4], aux2[4];
+            f32x4 aux[2], aux2[2];
             if (METRIC != COSINE) {
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) aux[g4] = *reinterpret_cast<const f32x4*>(&inv_lds[buf][8 * g4 + 4 * half]);
+                for (int rb = 0; rb < 2; ++rb) aux[rb] = *reinterpret_cast<const f32x4*>(&inv_lds[buf][16 * rb + 4 * kg]);
             }
             if (METRIC == EUCLIDEAN) {
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) aux2[g4] = *reinterpret_cast<const f32x4*>(&sqn_lds[buf][8 * g4 + 4 * half]);
+                for (int rb = 0; rb < 2; ++rb) aux2[rb] = *reinterpret_cast<const f32x4*>(&sqn_lds[buf][16 * rb + 4 * kg]);
             }
+            const bool partial = row0 + MF_ROWS > n_rows || !tile_live;  // partial last tile / repeated tail tile (wave-uniform)
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
-                float keys[16];
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
+                for (int qb = 0; qb < 2; ++qb) {
+                    float keys[8];  // rows 16 rb + 4 kg + jj
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        float key = acc[qt][4 * g4 + jj];                                   // cosine: x^.q
-                        if (METRIC == DOT) key *= aux[g4][jj];                              // x.q
-                        if (METRIC == EUCLIDEAN) key = 2.0f * key * aux[g4][jj] - aux2[g4][jj];  // |q|^2 - |x - q|^2
-                        keys[4 * g4 + jj] = key;
-                    }
-                }
-                if (row0 + MF_ROWS > n_rows || !tile_live) {  // partial last tile / repeated tail tile (wave-uniform)
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg)
-                        if (!tile_live || row0 + (uint32_t)((reg & 3) + 8 * (reg >> 2) + 4 * half) >= n_rows)
-                            keys[reg] = -INFINITY;
-                }
-                float m4[4];
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4)
-                    m4[g4] = fmaxf(fmaxf(keys[4 * g4], keys[4 * g4 + 1]), fmaxf(keys[4 * g4 + 2], keys[4 * g4 + 3]));
-                const float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-                if (MODE == 0) {
-                    run_max[qt] = fmaxf(run_max[qt], m);
-                } else if (__builtin_amdgcn_ballot_w64(m >= thr_q[qt]) != 0ull) {
-                    // Rare per wave-tile, but the WHOLE workgroup waits for the slowest wave at the next
-                    // barrier, and with 8 waves some wave takes this branch on most tiles: it must be
-                    // short.  No atomic (the wave appends to its own ring segment), 4-register groups
-                    // without a candidate are skipped with one ballot, slots come from ballot + mbcnt.
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        if (__builtin_amdgcn_ballot_w64(m4[g4] >= thr_q[qt]) == 0ull) continue;  // wave-uniform
+                    for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) {
-                            const int reg = 4 * g4 + jj;
-                            const bool is_cand = keys[reg] >= thr_q[qt] && keys[reg] > -INFINITY;  // masked rows are -inf; T_q may be too
-                            const unsigned long long mk = __builtin_amdgcn_ballot_w64(is_cand);
-                            if (mk != 0ull) {  // wave-uniform
-                                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32),
-                                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                                const uint32_t slot = my_cnt + rank;
-                                if (is_cand && slot < (uint32_t)SEG) {
-                                    const uint32_t e = (uint32_t)wave * SEG + slot;
-                                    ring_key[e] = keys[reg];
-                                    ring_pos[e] = row0 + (uint32_t)((reg & 3) + 8 * (reg >> 2) + 4 * half);
-                                    ring_q[e] = (unsigned short)((wave * QT + qt) * 32 + col);
+                            float key = acc[qt][rb][qb][jj];                                       // cosine: x^.q
+                            if (METRIC == DOT) key *= aux[rb][jj];                                 // x.q
+                            if (METRIC == EUCLIDEAN) key = 2.0f * key * aux[rb][jj] - aux2[rb][jj];  // |q|^2 - |x - q|^2
+                            if (partial && (!tile_live || row0 + (uint32_t)(16 * rb + 4 * kg + jj) >= n_rows)) key = -INFINITY;
+                            keys[4 * rb + jj] = key;
+                        }
+                    }
+                    float m2[2];
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+                        m2[rb] = fmaxf(fmaxf(keys[4 * rb], keys[4 * rb + 1]), fmaxf(keys[4 * rb + 2], keys[4 * rb + 3]));
+                    const float m = fmaxf(m2[0], m2[1]);
+                    const float tq = thr_q[qt][qb];
+                    if (MODE == 0) {
+                        run_max[qt][qb] = fmaxf(run_max[qt][qb], m);
+                    } else if (__builtin_amdgcn_ballot_w64(m >= tq) != 0ull) {
+                        // Rare per wave-tile, but the WHOLE workgroup waits for the slowest wave at the next
+                        // barrier, and with 8 waves some wave takes this branch on most tiles: it must be
+                        // short.  No atomic (the wave appends to its own ring segment), register groups without a
+                        // candidate are skipped with one ballot, slots come from ballot + mbcnt.
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb) {
+                            if (__builtin_amdgcn_ballot_w64(m2[rb] >= tq) == 0ull) continue;  // wave-uniform
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) {
+                                const float key = keys[4 * rb + jj];
+                                const bool is_cand = key >= tq && key > -INFINITY;  // masked rows are -inf; T_q may be too
+                                const unsigned long long mk = __builtin_amdgcn_ballot_w64(is_cand);
+                                if (mk != 0ull) {  // wave-uniform
+                                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32),
+                                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                                    const uint32_t slot = my_cnt + rank;
+                                    if (is_cand && slot < (uint32_t)SEG) {
+                                        const uint32_t e = (uint32_t)wave * SEG + slot;
+                                        ring_key[e] = key;
+                                        ring_pos[e] = row0 + (uint32_t)(16 * rb + 4 * kg + jj);
+                                        ring_q[e] = (unsigned short)((wave * QT + qt) * 32 + qb * 16 + c16);
+                                    }
+                                    my_cnt += (uint32_t)__popcll(mk);
                                 }
-                                my_cnt += (uint32_t)__popcll(mk);
                             }
                         }
                     }
@@ -333,11 +357,15 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
     }
     if (MODE == 0) {
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const float other = __shfl_xor(run_max[qt], 32);  // the two half-waves saw different rows of one query
-            const float mx = fmaxf(run_max[qt], other);
-            if (q_valid[qt] && half == 0 && blockIdx.x < n_groups) gmax[(size_t)q[qt] * n_groups + blockIdx.x] = enc_f(mx);
-        }
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                float mx = run_max[qt][qb];  // the four k-groups of lanes saw different rows of one query
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                if (q_valid[qt][qb] && kg == 0 && blockIdx.x < n_groups)
+                    gmax[(size_t)q[qt][qb] * n_groups + blockIdx.x] = enc_f(mx);
+            }
     }
 }
 
