@@ -807,13 +807,56 @@ def test_exact_select_rounds_for_k_above_64(V, O):
     gpu.add_rows(ids, rows, validate=False)
     ref = O.FlatOracle(dim, ids, rows)
     q = rows[999] + 0.001 * rng.standard_normal(dim)
+    gpu.force_path(V.PATH_EXACT_SELECT)  # keep the multi-list fast path (k <= 220) out of this test
     for m in (0, 1, 3):
         for k in (65, 128, 129, 200):
             assert_same(V, gpu.search_arrays(q, k, m), ref.search(q, k, m), (m, k))
             # 600 k rows allow 2 rounds (a round is cheaper than the sort only on big indexes, flat_index.cpp)
             assert V.last_path() == (V.PATH_EXACT_SELECT if k <= 128 else V.PATH_EXACT_SORT)
+    gpu.force_path(0)
     assert_same(V, gpu.search_arrays(q, 1000, 0), ref.search(q, 1000, 0), "k=1000")
     assert V.last_path() == V.PATH_EXACT_SORT
+    # unforced, the same queries sit on 201 tied rows: the multi-list fast path cannot certify them and hands on
+    for k in (65, 200):
+        assert_same(V, gpu.search_arrays(q, k, 0), ref.search(q, k, 0), ("unforced", k))
+        assert V.last_path() != V.PATH_FAST
+
+
+def test_multi_list_fast_path_for_k_up_to_220(V, O):
+    """60 < k <= 220: 2-4 partitions of 64 candidates rescored and ranked together, still ONE f32 scan; bit-identical to
+    the oracle, fast path on well-separated data, exact path when the bound cannot hold (ties at the cut)."""
+    rng = np.random.default_rng(6161)
+    n, dim = 200_000, 32
+    rows = unit_rows(rng, n, dim)
+    ids = permuted_ids(n)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    Q = unit_rows(rng, 3, dim)
+    fast = 0
+    for qi in range(3):
+        for m in range(4):
+            for k in (61, 64, 92, 93, 100, 156, 157, 220, 221):
+                assert_same(V, gpu.search_arrays(Q[qi], k, m), ref.search(Q[qi], k, m), (qi, m, k))
+                if k <= 220:
+                    fast += int(V.last_path() == V.PATH_FAST)
+                else:
+                    assert V.last_path() != V.PATH_FAST
+    assert fast >= 3 * 4 * 8 * 0.9, fast  # the bound holds on this data almost always
+    # ties across the cut: 100 copies of one row, k = 80 cuts through them
+    rows2 = rows.copy()
+    rows2[500:600] = rows2[499]
+    gpu2 = V.FlatIndex(dim)
+    gpu2.add_rows(ids, rows2, validate=False)
+    ref2 = O.FlatOracle(dim, ids, rows2)
+    assert_same(V, gpu2.search_arrays(rows2[499], 80, 0), ref2.search(rows2[499], 80, 0), "ties")
+    assert V.last_path() != V.PATH_FAST
+    # small index: fewer rows than candidates
+    gpu3 = V.FlatIndex(dim)
+    gpu3.add_rows(ids[:300], rows[:300], validate=False)
+    ref3 = O.FlatOracle(dim, ids[:300], rows[:300])
+    for k in (61, 100, 220, 300, 301):
+        assert_same(V, gpu3.search_arrays(Q[0], k, 1), ref3.search(Q[0], k, 1), ("small", k))
 
 
 def test_concurrent_writers_and_coalesced_readers_do_not_deadlock_or_corrupt(V, O):

@@ -502,6 +502,109 @@ __global__ __launch_bounds__(1024) void k_merge_finalize(const Cand32* __restric
     }
 }
 
+// K2 for 60 < k <= 220: the workgroup lists are cut into P partitions (any partition of the rows will do), each
+// keeps its own top 64, and all 64 P candidates are rescored and ranked together.  A row left out of partition
+// p's list has scan key <= that list's 64th key t_p, so the answer stands iff score[k-1] > max_p B(t_p) -- the
+// same proof as K2's, per partition.  On random data the 64th key of one of P partitions sits near global rank
+// 64 P, so k up to ~ 64 P - 30 is certified; anything else falls back to the exact kernels as before.
+constexpr int KMULTI_PARTS = 4;
+
+template <int METRIC>
+__global__ __launch_bounds__(1024) void k_merge_finalize_multi(const Cand32* __restrict__ lists, int n_lists,
+                                                               size_t part_stride, int n_parts,
+                                                               const double* __restrict__ master,
+                                                               const double* __restrict__ q64,
+                                                               const double* __restrict__ q_norms, uint32_t dim,
+                                                               uint32_t ld, uint64_t n_rows, uint32_t k, double R,
+                                                               SearchResultBlock* __restrict__ out)
+{
+    constexpr int NW = 16;
+    __shared__ Cand32 sh_lists[NW * WAVE];
+    __shared__ double tile[KP][RESCORE_CH + 1];
+    __shared__ double qtile[RESCORE_CH];
+    __shared__ uint32_t sh_pos[KMULTI_PARTS * KP];
+    __shared__ float sh_key[KMULTI_PARTS * KP];
+    __shared__ double sh_score[KMULTI_PARTS * KP];
+    __shared__ int sh_ncand[KMULTI_PARTS];
+    __shared__ int sh_flags;
+    __shared__ double sh_cut;
+    __shared__ int sh_has_cut;
+    const double Q = q_norms[0];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
+        sh_flags = 0;
+        sh_has_cut = 0;
+        sh_cut = 0.0;
+    }
+    // phase 1: per partition, n_lists <= 64 sorted lists -> its top 64
+    for (int p = 0; p < n_parts; ++p) {
+        TopList<float> L;
+        const int first = wave * 4;
+        int count = n_lists - first;
+        count = count < 0 ? 0 : (count > 4 ? 4 : count);
+        fold_lists4<float, Cand32>(L, lists + (size_t)p * part_stride, first, count);
+        block_merge<float, Cand32, NW>(L, sh_lists);
+        if (wave == 0) {
+            sh_pos[p * KP + lane] = L.pos;
+            sh_key[p * KP + lane] = L.key;
+            const unsigned long long real = __ballot(L.pos != POS_SENTINEL);
+            if (lane == 0) sh_ncand[p] = __popcll(real);
+        }
+        __syncthreads();
+    }
+    // phase 2: exact f64 rescoring, 64 rows at a time through the same LDS tile
+    for (int p = 0; p < n_parts; ++p) {
+        Acc64<METRIC> A;
+        rescore_rows<METRIC, 1024>(master, q64, dim, sh_pos + p * KP, sh_ncand[p], tile, qtile, A);
+        if (wave == 0) sh_score[p * KP + lane] = lane < sh_ncand[p] ? A.score() : 0.0;
+        __syncthreads();
+    }
+    // phase 3: rank all candidates by (score desc, pos asc), bound check, emit
+    const int t = threadIdx.x;
+    const int total_slots = n_parts * KP;
+    const bool valid = t < total_slots && (t % KP) < sh_ncand[t / KP];
+    const double sc = valid ? sh_score[t] : 0.0;
+    const uint32_t my_pos = t < total_slots ? sh_pos[t] : POS_SENTINEL;
+    if (valid && sc != sc) atomicOr(&sh_flags, (int)(RESULT_HAS_NAN | RESULT_NEEDS_EXACT));
+    int rank = 0;
+    for (int j = 0; j < total_slots; ++j) {
+        if ((j % KP) >= sh_ncand[j / KP]) continue;
+        const double sj = sh_score[j];
+        const uint32_t pj = sh_pos[j];
+        rank += (sj > sc || (sj == sc && pj < my_pos)) ? 1 : 0;
+    }
+    const uint32_t k_eff = (uint64_t)k < n_rows ? k : (uint32_t)n_rows;
+    if (valid && rank == (int)k_eff - 1) {
+        sh_cut = sc;
+        sh_has_cut = 1;
+    }
+    __syncthreads();
+    if (valid && rank < (int)k_eff) {
+        out[rank / KP].pos[rank % KP] = my_pos;
+        out[rank / KP].score[rank % KP] = sc;
+    }
+    if (t == 0) {
+        uint32_t flags = (uint32_t)sh_flags;
+        int total = 0;
+        double B = -1.0e300;
+        bool excluded_rows = false;
+        for (int p = 0; p < n_parts; ++p) {
+            total += sh_ncand[p];
+            if (sh_ncand[p] == KP) {  // a full list: rows behind its 64th key exist (or may exist)
+                excluded_rows = true;
+                const double bp = bound_for_key<METRIC>(sh_key[p * KP + KP - 1], ld, R, Q, 0.0);
+                B = bp > B ? bp : B;
+            }
+        }
+        if (!sh_has_cut || (uint32_t)total < k_eff) flags |= RESULT_NEEDS_EXACT;
+        else if (excluded_rows && !(sh_cut > B)) flags |= RESULT_NEEDS_EXACT;
+        if ((uint64_t)total < n_rows && !excluded_rows) flags |= RESULT_NEEDS_EXACT;  // short lists that do not cover the index
+        out[0].n_out = k_eff;
+        out[0].flags = flags;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Exact path
 // ---------------------------------------------------------------------------------------------
@@ -1092,6 +1195,23 @@ hipError_t launch_merge_finalize(hipStream_t s, int metric, Cand32* partials, in
         constexpr int MM = decltype(M)::value;
         hipLaunchKernelGGL((k_merge_finalize<MM>), dim3(nq), dim3(1024), 0, s, lists, n_lists, stride, master, q64,
                            q_norms, dim, ld, n_rows, k, max_row_norm, in_extra, out);
+        return hipGetLastError();
+    });
+}
+
+hipError_t launch_merge_finalize_multi(hipStream_t s, int metric, Cand32* partials, int n_lists_total, int n_parts,
+                                       const double* master, const double* q64, const double* q_norm, uint32_t dim,
+                                       uint64_t n_rows, uint32_t k, double max_row_norm, SearchResultBlock* out)
+{
+    if (n_parts < 2 || n_parts > KMULTI_PARTS || n_lists_total % n_parts != 0) return hipErrorInvalidValue;
+    const uint32_t ld = (dim + 3u) & ~3u;
+    int n_lists = n_lists_total / n_parts;  // consecutive workgroup lists form one partition
+    size_t stride = (size_t)n_lists * KP;
+    const Cand32* lists = reduce_lists<float, Cand32>(s, partials, &n_lists, &stride, n_parts, partials + PARTIALS32_LISTS * KP);
+    return dispatch_metric(metric, [&](auto M) -> hipError_t {
+        constexpr int MM = decltype(M)::value;
+        hipLaunchKernelGGL((k_merge_finalize_multi<MM>), dim3(1), dim3(1024), 0, s, lists, n_lists, stride, n_parts, master,
+                           q64, q_norm, dim, ld, n_rows, k, max_row_norm, out);
         return hipGetLastError();
     });
 }

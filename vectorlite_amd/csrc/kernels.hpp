@@ -80,6 +80,12 @@ hipError_t launch_scan(hipStream_t s, int metric, const float* slab, const float
 // rows, rank by (score desc, pos asc), run the exactness bound check, write the result block.
 // One workgroup per query: `partials` holds nq x n_lists lists (query-major), q64 is [nq, dim],
 // q_norms[nq] the f64 query norms, out[nq] the result blocks.
+// 60 < k <= KMULTI_MAX: the scan's workgroup lists cut into n_parts partitions of 64 candidates each, rescored and
+// ranked together; out = n_parts result blocks (ranks 64 i .. 64 i + 63 in block i; n_out and flags in block 0).
+constexpr int KMULTI_MAX = 220;
+hipError_t launch_merge_finalize_multi(hipStream_t s, int metric, Cand32* partials, int n_lists_total, int n_parts,
+                                       const double* master, const double* q64, const double* q_norm, uint32_t dim,
+                                       uint64_t n_rows, uint32_t k, double max_row_norm, SearchResultBlock* out);
 hipError_t launch_merge_finalize(hipStream_t s, int metric, Cand32* partials, int n_lists, int nq,
                                  const double* master, const double* q64, const double* q_norms, uint32_t dim,
                                  uint64_t n_rows, uint32_t k, double max_row_norm, SearchResultBlock* out,
