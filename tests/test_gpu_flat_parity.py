@@ -730,7 +730,7 @@ def test_seeded_fuzz_adversarial_values(V, O):
             Q.append(rng.integers(-2, 3, size=dim).astype(np.float64))
         for q in Q:
             for m in range(4):
-                for k in (1, 10, n):
+                for k in (1, 10, n) + ((100, 200) if n >= 700 else ()):  # 100 / 200: the multi-list fast path
                     assert_same(V, gpu.search_arrays(q, k, m), ref.search(q, k, m), (case, kind, dim, n, m, k))
         Qb = np.stack(Q + [rows[i % n] * 0.5 for i in range(9 - len(Q))])
         m = case % 4
