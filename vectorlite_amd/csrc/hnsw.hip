@@ -407,6 +407,8 @@ __global__ __launch_bounds__(256) void k_hnsw_insert_search(HnswGraphView g, uin
         for (uint32_t c = lane; c < g.ld; c += 64) q32[c] = g.slab[(size_t)p * g.ld + c];
         const float q_inv = g.inv_norm[p];
         __builtin_amdgcn_wave_barrier();
+        // distance of p to itself in this arithmetic: exact copies of p among the candidates show exactly this key
+        const unsigned long long d_self = read_lane(row_distance_f32<METRIC>(g, p, q32, q_inv, half), 0);
         BeamList<S> L;
         L.init();
         epoch += 1;
@@ -447,20 +449,31 @@ __global__ __launch_bounds__(256) void k_hnsw_insert_search(HnswGraphView g, uin
             unsigned long long seld = 0;
             uint32_t nsel = 0;
             unsigned long long kept_lo = 0, kept_hi = 0;  // which beam entries were kept
+            // Exact copies of p (more than M0 of them would otherwise fill every slot and cut the copies off from
+            // the rest of the graph) get at most a quarter of the list; the other slots go to distinct rows.
+            const uint32_t dup_cap = cap / 4 > 0 ? cap / 4 : 1;
+            uint32_t ndup = 0;
             for (int ci = 0; ci < total && nsel < cap; ++ci) {
                 unsigned long long dc;
                 uint32_t cv;
                 L.get(ci, dc, cv);
                 cv &= ~EXPANDED;
+                const bool is_dup = dc == d_self;
+                if (is_dup && ndup >= dup_cap) continue;  // wave-uniform
                 bool bad = false;
-                if (nsel > 0 && (flags & 1u)) {
+                if (nsel > 0 && (flags & 1u) && !is_dup) {
                     for (uint32_t c = lane; c < g.ld; c += 64) cand32[c] = g.slab[(size_t)cv * g.ld + c];
                     const float c_inv = g.inv_norm[cv];
                     __builtin_amdgcn_wave_barrier();
                     for (uint32_t base = 0; base < nsel; base += 32) {  // kept neighbours in rounds of 32 lane pairs
                         const uint32_t kj = base + (uint32_t)nl;
                         const uint32_t kn = (uint32_t)__shfl((int)selv, (int)(kj & 63u));
-                        if (kj < nsel) bad = bad || row_distance_f32<METRIC>(g, kn, cand32, c_inv, half) < dc;
+                        // kept neighbours that are copies of p itself (kd == d_self) say nothing about direction:
+                        // every candidate is exactly as far from them as from p, so they take no part in the test
+                        const unsigned long long kd =
+                            ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(seld >> 32), (int)(kj & 63u)) << 32) |
+                            (uint32_t)__shfl((int)(uint32_t)seld, (int)(kj & 63u));
+                        if (kj < nsel && kd != d_self) bad = bad || row_distance_f32<METRIC>(g, kn, cand32, c_inv, half) < dc;
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -470,6 +483,7 @@ __global__ __launch_bounds__(256) void k_hnsw_insert_search(HnswGraphView g, uin
                         seld = dc;
                     }
                     ++nsel;
+                    ndup += is_dup ? 1u : 0u;
                     if (ci < 64) kept_lo |= 1ull << ci;
                     else kept_hi |= 1ull << (ci - 64);
                 }
@@ -481,6 +495,10 @@ __global__ __launch_bounds__(256) void k_hnsw_insert_search(HnswGraphView g, uin
                     unsigned long long dc;
                     uint32_t cv;
                     L.get(ci, dc, cv);
+                    if (dc == d_self) {  // copies of p stay capped in the back-fill too
+                        if (ndup >= dup_cap) continue;
+                        ++ndup;
+                    }
                     if ((uint32_t)lane == nsel) {
                         selv = cv & ~EXPANDED;
                         seld = dc;
