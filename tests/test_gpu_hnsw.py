@@ -297,3 +297,25 @@ def test_k_above_the_beam_limit_is_answered_exactly(V, O):
         assert got_d == sorted(got_d)                                   # nearest first
         assert max(got_d) <= sorted(d.values())[want_n - 1]              # exactly the want_n nearest (ties aside)
         assert all(r.score == O.hnsw_score(d[int(r.id) - 500], 1) for r in res)
+
+
+def test_duplicate_heavy_index_stays_connected(V):
+    """36 distinct rows, ~80 copies each (more copies than a neighbour list holds): copies of a node may take at
+    most a quarter of its list, so the cliques stay linked to the rest of the graph and k = 128 is served in full."""
+    rng = np.random.default_rng(5603)
+    n = 3000
+    rows = np.round(rng.standard_normal((n, 2)) @ rng.standard_normal((2, 2)))
+    assert len(np.unique(rows, axis=0)) < 80
+    ids = np.arange(n, dtype=np.uint64)
+    for metric in (V.SimilarityMetric.Euclidean, V.SimilarityMetric.Manhattan):
+        idx = V.HNSWIndex(2, metric)
+        idx.add_rows(ids, rows)
+        Q = rows[:8] + 0.05
+        bi, bs, bn = idx.search_batch(Q, 128, metric)
+        assert bn.tolist() == [128] * 8
+        flat = V.FlatIndex(2)
+        flat.add_rows(ids, rows, validate=False)
+        hi, hs, hn = idx.search_batch(Q, 10, metric, ef=64)
+        fi, fs, fn = flat.search_batch(Q, 10, metric)
+        # ties everywhere: compare scores, not ids
+        assert np.allclose(np.sort(1.0 / hs[:, :10] - 1.0, axis=1), np.sort(1.0 / fs - 1.0, axis=1), atol=2e-3)
