@@ -20,6 +20,10 @@ use crate::{SearchResult, SimilarityMetric, Vector, VectorIndex};
 pub struct vl_index {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct vl_vlc_doc {
+    _private: [u8; 0],
+}
 
 extern "C" {
     fn vl_flat_create(dim: u64, device: c_int, out: *mut *mut vl_index) -> c_int;
@@ -35,6 +39,11 @@ extern "C" {
     fn vl_index_get_vector(h: *const vl_index, id: u64, out: *mut f64) -> c_int;
     fn vl_index_export(h: *const vl_index, out_ids: *mut u64, out_values: *mut f64) -> c_int;
     fn vl_index_set_coalescing(h: *mut vl_index, max_batch: c_int, window_us: c_int) -> c_int;
+    fn vl_index_search_batch(h: *const vl_index, queries: *const f64, nq: u64, q_len: u64, k: u64, metric: c_int, out_ids: *mut u64, out_scores: *mut f64, out_n: *mut u64) -> c_int;
+    fn vl_index_search_ef(h: *const vl_index, queries: *const f64, nq: u64, q_len: u64, k: u64, ef: u32, metric: c_int, out_ids: *mut u64, out_scores: *mut f64, out_n: *mut u64) -> c_int;
+    fn vl_vlc_open(path: *const c_char, out: *mut *mut vl_vlc_doc) -> c_int;
+    fn vl_vlc_close(doc: *mut vl_vlc_doc);
+    fn vl_vlc_build_index(doc: *const vl_vlc_doc, device: c_int, out: *mut *mut vl_index) -> c_int;
     fn vl_last_error() -> *const c_char;
     fn vl_last_dim_mismatch(expected: *mut u64, actual: *mut u64);
 }
@@ -175,6 +184,22 @@ impl GpuFlatIndex {
         // tokio workers search concurrently under RwLock::read: let them share slab passes
         unsafe { vl_index_set_coalescing(raw, 64, 200) };
         GpuFlatIndex(Handle { raw, dim, side })
+    }
+}
+
+impl GpuFlatIndex {
+    /// nq independent searches sharing slab passes (no reference counterpart); row i is exactly `search(queries[i])`.
+    pub fn search_batch(&self, queries: &[f64], nq: usize, k: usize, metric: SimilarityMetric) -> VectorLiteResult<Vec<Vec<(u64, f64)>>> {
+        let dim = self.0.dim;
+        assert_eq!(queries.len(), nq * dim);
+        let (mut ids, mut scores, mut n) = (vec![0u64; nq * k.max(1)], vec![0f64; nq * k.max(1)], vec![0u64; nq]);
+        let rc = unsafe {
+            vl_index_search_batch(self.0.raw, queries.as_ptr(), nq as u64, dim as u64, k as u64, metric_code(metric), ids.as_mut_ptr(), scores.as_mut_ptr(), n.as_mut_ptr())
+        };
+        if rc != VL_OK {
+            return Err(VectorLiteError::InternalError(last_error()));
+        }
+        Ok((0..nq).map(|q| (0..n[q] as usize).map(|i| (ids[q * k + i], scores[q * k + i])).collect()).collect())
     }
 }
 

@@ -12,6 +12,7 @@ RUST_TO_C = {
     "*const u64": "const uint64_t *", "*mut u64": "uint64_t *",
     "*const vl_index": "const vl_index *", "*mut vl_index": "vl_index *", "*mut *mut vl_index": "vl_index **",
     "*const c_char": "const char *", "": "void",
+    "*const vl_vlc_doc": "const vl_vlc_doc *", "*mut vl_vlc_doc": "vl_vlc_doc *", "*mut *mut vl_vlc_doc": "vl_vlc_doc **",
 }
 
 
