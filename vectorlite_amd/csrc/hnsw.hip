@@ -314,19 +314,39 @@ __device__ __forceinline__ void next_layer(BeamList<S>& L, uint32_t* stamps, uin
         if (L.v[s] != HNSW_NONE) stamps[L.v[s] & ~EXPANDED] = epoch;
 }
 
+// convert_distance_to_similarity(d_u64 as f64 / 1000.0, metric) (src/index/hnsw.rs:51-75, :478-479)
+template <int METRIC>
+__device__ __forceinline__ double hnsw_score_dev(unsigned long long d_u64)
+{
+    const double distance = (double)d_u64 / 1000.0;
+    if (METRIC == EUCLIDEAN || METRIC == MANHATTAN) return 1.0 / (1.0 + distance);
+    if (METRIC == COSINE) return 1.0 - distance / 1000.0;
+    double v = (1000.0 - distance) / 1000.0;
+    if (v < 0.0) v = 0.0;
+    if (v > 1.0) v = 1.0;
+    return v;
+}
+
 template <int METRIC, int S>
 __global__ __launch_bounds__(256) void k_hnsw_search(HnswGraphView g, const double* __restrict__ queries, uint32_t nq,
-                                                     uint32_t ef, uint32_t entry, int max_level,
-                                                     HnswHit* __restrict__ out)
+                                                     uint32_t ef, uint32_t entry, int max_level, uint32_t max_candidates,
+                                                     uint32_t k_stride, unsigned long long* __restrict__ out_ids,
+                                                     double* __restrict__ out_scores, unsigned long long* __restrict__ out_n,
+                                                     unsigned long long* __restrict__ stat_evals)
 {
-    extern __shared__ double q_lds[];  // per wave: [dim] f64 query, then [ld] f32 copy (zero padded)
+    // per wave: [ld] f32 query (zero padded), [dim] f64 query, then two (key, node) tables of HNSW_MAX_EF entries
+    extern __shared__ double q_lds[];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const uint32_t slot = blockIdx.x * 4 + wave;
     if (slot >= g.n_slots) return;
-    const size_t per_wave = ((size_t)g.ld / 2 + g.dim + 1) & ~(size_t)1;  // in doubles, 16-byte granules
-    float* q32 = reinterpret_cast<float*>(q_lds + (size_t)wave * per_wave);
-    double* q = q_lds + (size_t)wave * per_wave + g.ld / 2;
+    const size_t q_words = ((size_t)g.ld / 2 + g.dim + 1) & ~(size_t)1;  // in doubles, 16-byte granules
+    const size_t per_wave = q_words + 3 * (size_t)HNSW_MAX_EF;            // + 2 x (8 B key) + 2 x (4 B node) per entry
+    double* base = q_lds + (size_t)wave * per_wave;
+    float* q32 = reinterpret_cast<float*>(base);
+    double* q = base + g.ld / 2;
+    unsigned long long* t_key = reinterpret_cast<unsigned long long*>(base + q_words);  // [2][HNSW_MAX_EF]
+    uint32_t* t_node = reinterpret_cast<uint32_t*>(t_key + 2 * HNSW_MAX_EF);             // [2][HNSW_MAX_EF]
     uint32_t* stamps = g.stamps + (size_t)slot * g.cap;
     uint32_t epoch = g.epochs[slot];
 
@@ -357,25 +377,66 @@ __global__ __launch_bounds__(256) void k_hnsw_search(HnswGraphView g, const doub
             next_layer(L, stamps, epoch);
         }
         beam_layer_f32<METRIC, S>(g, q32, q_inv, 0, stamps, epoch, L, (int)ef, &evals);
-        // the final beam gets the reference's own callback value: one lane walks one f64 row in index order
-        // (src/index/hnsw.rs:113-174); the host orders the beam by it
+
+        // (1) the final beam gets the reference's own callback value: one lane walks one f64 row in index order
+        //     (src/index/hnsw.rs:113-174)
+        uint32_t n_real = 0;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const uint32_t j = s * 64 + lane;
             const uint32_t node = L.v[s] == HNSW_NONE ? HNSW_NONE : (L.v[s] & ~EXPANDED);
-            unsigned long long exact = ~0ull;
             const bool real = j < ef && node != HNSW_NONE;
+            unsigned long long exact = ~0ull;
             if (real) exact = row_distance<METRIC>(g.master + (size_t)node * g.dim, q, g.dim);
-            evals += (uint32_t)__popcll(__ballot(real));
-            if (j < ef) {
-                HnswHit h;
-                h.dist = exact;  // bit pattern of the reference's f64 value BEFORE its `as u64`: the host orders by it, then truncates
-                h.node = node;
-                h.evals = 0u;
-                out[(size_t)qi * ef + j] = h;
+            n_real += (uint32_t)__popcll(__ballot(real));
+            if (j < (uint32_t)HNSW_MAX_EF) {
+                t_key[j] = exact;
+                t_node[j] = node;
             }
         }
-        if (lane == 0) out[(size_t)qi * ef].evals = evals;
+        evals += n_real;
+        __builtin_amdgcn_wave_barrier();
+        // (2) the beam in (distance, node) order -- `neighbors` after hnsw.nearest (:454-466), ties of the truncated
+        //     u64 broken by the true distance: every entry counts the entries in front of it
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint32_t j = s * 64 + lane;
+            const unsigned long long kj = t_key[j < (uint32_t)HNSW_MAX_EF ? j : 0];
+            const uint32_t nj = t_node[j < (uint32_t)HNSW_MAX_EF ? j : 0];
+            if (j < ef && nj != HNSW_NONE) {
+                uint32_t rank = 0;
+                for (uint32_t i = 0; i < ef; ++i) {
+                    const unsigned long long ki = t_key[i];
+                    const uint32_t ni = t_node[i];
+                    rank += (ni != HNSW_NONE && (ki < kj || (ki == kj && ni < nj))) ? 1u : 0u;
+                }
+                t_key[HNSW_MAX_EF + rank] = kj;
+                t_node[HNSW_MAX_EF + rank] = nj;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // (3) tombstoned nodes dropped (:475), the closest max_candidates kept (:442-448), distances -> scores
+        //     (:478-479); the score never increases with the distance, so this order IS the stable sort by score (:493)
+        uint32_t kept = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint32_t r = s * 64 + lane;
+            const bool in = r < n_real;
+            const uint32_t node = in ? t_node[HNSW_MAX_EF + r] : 0u;
+            const bool alive = in && g.live[node] != 0;
+            const unsigned long long mk = __ballot(alive);
+            const uint32_t pos = kept + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            if (alive && pos < max_candidates) {
+                const double scaled = __longlong_as_double((long long)t_key[HNSW_MAX_EF + r]);
+                out_ids[(size_t)qi * k_stride + pos] = g.node_id[node];
+                out_scores[(size_t)qi * k_stride + pos] = hnsw_score_dev<METRIC>(rust_as_u64(scaled));
+            }
+            kept += (uint32_t)__popcll(mk);
+        }
+        if (lane == 0) {
+            out_n[qi] = kept < max_candidates ? kept : max_candidates;
+            if (stat_evals) atomicAdd(stat_evals, (unsigned long long)evals);
+        }
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) g.epochs[slot] = epoch;
@@ -616,7 +677,7 @@ hipError_t dispatch_metric(int metric, F&& f)
 
 // Dynamic LDS above the 64 KB default needs the per-kernel attribute (gfx950 has 160 KB per CU); raised once
 // per kernel to the ceiling this file ever asks for.
-constexpr size_t HNSW_LDS_MAX = 152 * 1024;
+constexpr size_t HNSW_LDS_MAX = 160 * 1024;
 template <typename K>
 hipError_t allow_big_lds(K kernel, size_t lds)
 {
@@ -644,11 +705,14 @@ int grid_for(const HnswGraphView& g, uint32_t work)
 }  // namespace
 
 hipError_t launch_hnsw_search(hipStream_t s, int metric, const HnswGraphView& g, const double* queries, uint32_t nq,
-                              uint32_t ef, uint32_t entry, int max_level, HnswHit* out)
+                              uint32_t ef, uint32_t entry, int max_level, uint32_t max_candidates, uint32_t k_stride,
+                              unsigned long long* out_ids, double* out_scores, unsigned long long* out_n,
+                              unsigned long long* stat_evals)
 {
     if (nq == 0) return hipSuccess;
-    if (ef == 0 || ef > (uint32_t)HNSW_MAX_EF || g.m0 > 64 || g.m > 64) return hipErrorInvalidValue;
-    const size_t lds = (size_t)4 * ((((size_t)g.ld / 2 + g.dim + 1) & ~(size_t)1)) * sizeof(double);
+    if (ef == 0 || ef > (uint32_t)HNSW_MAX_EF || g.m0 > 64 || g.m > 64 || max_candidates > k_stride) return hipErrorInvalidValue;
+    const size_t q_words = ((size_t)g.ld / 2 + g.dim + 1) & ~(size_t)1;
+    const size_t lds = (size_t)4 * (q_words + 3 * (size_t)HNSW_MAX_EF) * sizeof(double);
     if (lds > HNSW_LDS_MAX) return hipErrorInvalidValue;
     const int grid = grid_for(g, nq);
     return dispatch_metric(metric, [&](auto M) -> hipError_t {
@@ -656,7 +720,8 @@ hipError_t launch_hnsw_search(hipStream_t s, int metric, const HnswGraphView& g,
         auto launch = [&](auto kern) -> hipError_t {
             const hipError_t e = allow_big_lds(kern, lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, g, queries, nq, ef, entry, max_level, out);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, g, queries, nq, ef, entry, max_level, max_candidates,
+                               k_stride, out_ids, out_scores, out_n, stat_evals);
             return hipGetLastError();
         };
         return ef <= 64 ? launch(k_hnsw_search<MM, 1>) : launch(k_hnsw_search<MM, 2>);

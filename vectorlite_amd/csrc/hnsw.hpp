@@ -42,18 +42,20 @@ struct HnswGraphView {
     uint32_t* epochs;             // [n_slots]
     uint32_t n_slots;
     uint64_t cap;
+    // result post-processing on the device (query walks)
+    const unsigned long long* node_id;  // [cap] node -> caller's id
+    const uint8_t* live;                // [cap] 0 = tombstoned (src/index/hnsw.rs:405-411)
 };
 
-struct HnswHit {  // one neighbour returned by a walk
-    unsigned long long dist;  // query walk: f64 bit pattern of Metric::distance's value before `as u64` (~0 = empty slot)
-    uint32_t node;
-    uint32_t evals;  // entry 0 of a query: distance evaluations of the whole walk; else 0
-};
-
-// Query-time walk: nq queries (f64 [nq, dim]) -> out[nq][ef] sorted by (dist asc, node asc),
-// unused entries have node = HNSW_NONE.
+// Query-time walk of nq queries (f64 [nq, dim]) with beam width ef, finished on the device the way
+// HNSWIndex::search finishes it on the host (src/index/hnsw.rs:468-495): the beam in (Metric::distance, node)
+// order, tombstoned nodes dropped, the closest max_candidates kept, distances converted to scores
+// (convert_distance_to_similarity), ordered by score (already is: the score never increases with the distance).
+// out_ids / out_scores are [nq, k_stride], out_n is [nq]; stat_evals (optional) accumulates distance evaluations.
 hipError_t launch_hnsw_search(hipStream_t s, int metric, const HnswGraphView& g, const double* queries, uint32_t nq,
-                              uint32_t ef, uint32_t entry, int max_level, HnswHit* out);
+                              uint32_t ef, uint32_t entry, int max_level, uint32_t max_candidates, uint32_t k_stride,
+                              unsigned long long* out_ids, double* out_scores, unsigned long long* out_n,
+                              unsigned long long* stat_evals);
 
 // Build phase A: the rows [first, first+n) are new nodes; each walks the graph that holds the
 // nodes < first (entry/max_level describe it) with beam width ef_construction and writes its own

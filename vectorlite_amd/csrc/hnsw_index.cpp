@@ -103,6 +103,8 @@ int HnswIndex::create(uint64_t dim, int metric, const HnswParams& p, int device,
     h->store_.reset(st);
     VL_HIP(hipSetDevice(device));
     VL_HIP(hipStreamCreateWithFlags(&h->stream_, hipStreamNonBlocking));
+    VL_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_stat_evals_), sizeof(unsigned long long)));
+    VL_HIP(hipMemset(h->d_stat_evals_, 0, sizeof(unsigned long long)));
     *out = h.release();
     return OK;
 }
@@ -112,11 +114,11 @@ HnswIndex::~HnswIndex()
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     void* dev[] = {d_nbr0_, d_dist0_, d_cnt0_, d_level_, d_upper_off_, d_nbrU_, d_distU_, d_cntU_,
-                   d_lock_, d_stamps_, d_epochs_, d_q_, d_hits_};
+                   d_lock_, d_stamps_, d_epochs_, d_q_, d_out_, d_node_id_, d_live_, d_stat_evals_};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     if (h_q_) (void)hipHostFree(h_q_);
-    if (h_hits_) (void)hipHostFree(h_hits_);
+    if (h_out_) (void)hipHostFree(h_out_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -149,6 +151,8 @@ HnswGraphView HnswIndex::view() const
     g.epochs = d_epochs_;
     g.n_slots = n_slots_;
     g.cap = g_cap_;
+    g.node_id = d_node_id_;
+    g.live = d_live_;
     return g;
 }
 
@@ -166,6 +170,8 @@ int HnswIndex::ensure_graph(uint64_t nodes, uint64_t upper_slots)
         VL_TRY(regrow(&d_level_, g_cap_, nc, stream_, true));
         VL_TRY(regrow(&d_upper_off_, g_cap_, nc, stream_, true));
         VL_TRY(regrow(&d_lock_, g_cap_, nc, stream_, true));
+        VL_TRY(regrow(&d_node_id_, g_cap_, nc, stream_, true));
+        VL_TRY(regrow(&d_live_, g_cap_, nc, stream_, true));
         // visited stamps: one u32 per node per concurrently walking wave, at most ~8 GB
         uint64_t slots = (8ull << 30) / (nc * sizeof(uint32_t));
         slots = std::min<uint64_t>(slots, 4096);
@@ -287,6 +293,10 @@ int HnswIndex::add_bulk(const uint64_t* ids, const double* values, uint64_t n, b
         VL_HIP(hipStreamSynchronize(stream_));
     }
 
+    // device copies used by the query kernel's result stage
+    VL_HIP(hipMemcpyAsync(d_node_id_ + first, ids, n_take * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
+    VL_HIP(hipMemsetAsync(d_live_ + first, 1, n_take, stream_));
+    VL_HIP(hipStreamSynchronize(stream_));
     node_id_.insert(node_id_.end(), ids, ids + n_take);
     live_.insert(live_.end(), n_take, 1);
     for (uint64_t i = 0; i < n_take; ++i) id_to_node_[ids[i]] = (uint32_t)(first + i);
@@ -304,6 +314,9 @@ int HnswIndex::remove(uint64_t id)
         return ERR_NOT_FOUND;
     }
     live_[it->second] = 0;  // tombstone: the node stays in the graph and is still walked (:407)
+    VL_HIP(hipSetDevice(device_));
+    VL_HIP(hipMemsetAsync(d_live_ + it->second, 0, 1, stream_));
+    VL_HIP(hipStreamSynchronize(stream_));
     id_to_node_.erase(it);
     --live_count_;
     return OK;
@@ -323,7 +336,13 @@ int HnswIndex::get_vector(uint64_t id, double* out) const
 void HnswIndex::walk_stats(uint64_t* queries, uint64_t* distance_evals) const
 {
     if (queries) *queries = stat_queries_.load();
-    if (distance_evals) *distance_evals = stat_evals_.load();
+    if (distance_evals) {
+        unsigned long long dev = 0;
+        std::lock_guard<std::mutex> sg(search_mu_);  // no walk in flight while the counter is read
+        if (d_stat_evals_ && hipSetDevice(device_) == hipSuccess)
+            (void)hipMemcpy(&dev, d_stat_evals_, sizeof dev, hipMemcpyDeviceToHost);
+        *distance_evals = stat_evals_.load() + dev;
+    }
 }
 
 int HnswIndex::clone(HnswIndex** out) const
@@ -337,6 +356,8 @@ int HnswIndex::clone(HnswIndex** out) const
     VL_TRY(store_->clone(&st));
     c->store_.reset(st);
     VL_HIP(hipStreamCreateWithFlags(&c->stream_, hipStreamNonBlocking));
+    VL_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_stat_evals_), sizeof(unsigned long long)));
+    VL_HIP(hipMemset(c->d_stat_evals_, 0, sizeof(unsigned long long)));
     if (n_nodes_) {
         VL_TRY(c->ensure_graph(n_nodes_, n_upper_));
         auto copy = [&](void* dst, const void* src, size_t bytes) -> int {
@@ -351,6 +372,8 @@ int HnswIndex::clone(HnswIndex** out) const
         VL_TRY(copy(c->d_nbrU_, d_nbrU_, n_upper_ * params_.m * sizeof(uint32_t)));
         VL_TRY(copy(c->d_distU_, d_distU_, n_upper_ * params_.m * sizeof(unsigned long long)));
         VL_TRY(copy(c->d_cntU_, d_cntU_, n_upper_ * sizeof(uint32_t)));
+        VL_TRY(copy(c->d_node_id_, d_node_id_, n_nodes_ * sizeof(unsigned long long)));
+        VL_TRY(copy(c->d_live_, d_live_, n_nodes_ * sizeof(uint8_t)));
         VL_HIP(hipStreamSynchronize(c->stream_));
     }
     c->level_ = level_;
@@ -402,7 +425,7 @@ int HnswIndex::max_id(uint64_t* out) const
 // ---------------------------------------------------------------------------------------------
 // search (src/index/hnsw.rs:415-496)
 // ---------------------------------------------------------------------------------------------
-int HnswIndex::ensure_search_scratch(uint64_t nq, uint32_t ef) const
+int HnswIndex::ensure_search_scratch(uint64_t nq, uint64_t k) const
 {
     const uint64_t qn = nq * dim_;
     if (qn > q_cap_) {
@@ -415,16 +438,16 @@ int HnswIndex::ensure_search_scratch(uint64_t nq, uint32_t ef) const
         VL_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_q_), qn * sizeof(double), hipHostMallocDefault));
         q_cap_ = qn;
     }
-    const uint64_t hn = nq * ef;
-    if (hn > hits_cap_) {
-        if (d_hits_) (void)hipFree(d_hits_);
-        if (h_hits_) (void)hipHostFree(h_hits_);
-        d_hits_ = nullptr;
-        h_hits_ = nullptr;
-        hits_cap_ = 0;
-        VL_HIP(hipMalloc(reinterpret_cast<void**>(&d_hits_), hn * sizeof(HnswHit)));
-        VL_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_hits_), hn * sizeof(HnswHit), hipHostMallocDefault));
-        hits_cap_ = hn;
+    const uint64_t words = nq * (2 * k + 1);
+    if (words > out_cap_) {
+        if (d_out_) (void)hipFree(d_out_);
+        if (h_out_) (void)hipHostFree(h_out_);
+        d_out_ = nullptr;
+        h_out_ = nullptr;
+        out_cap_ = 0;
+        VL_HIP(hipMalloc(reinterpret_cast<void**>(&d_out_), words * sizeof(unsigned long long)));
+        VL_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_out_), words * sizeof(unsigned long long), hipHostMallocDefault));
+        out_cap_ = words;
     }
     return OK;
 }
@@ -464,18 +487,6 @@ int HnswIndex::search_exact_fallback(const double* query, uint64_t k, uint64_t* 
     *out_n = res.size();
     return OK;
 }
-
-namespace {
-// Rust `f64 as u64` (truncation toward zero, saturating, NaN -> 0) of the f64 whose bits are `key`
-uint64_t rust_as_u64_host(uint64_t key)
-{
-    double v;
-    std::memcpy(&v, &key, sizeof v);
-    if (!(v > 0.0)) return 0;
-    if (v >= 18446744073709551616.0) return ~0ull;
-    return (uint64_t)v;
-}
-}  // namespace
 
 int HnswIndex::search(const double* query, uint64_t q_len, uint64_t k, int metric, uint32_t ef, uint64_t* out_ids,
                       double* out_scores, uint64_t* out_n) const
@@ -559,51 +570,27 @@ int HnswIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_len, 
 
     VL_HIP(hipSetDevice(device_));
     std::lock_guard<std::mutex> sg(search_mu_);
-    VL_TRY(ensure_search_scratch(nq, (uint32_t)ef_walk));
+    VL_TRY(ensure_search_scratch(nq, k));
     std::memcpy(h_q_, queries, nq * dim_ * sizeof(double));
     VL_HIP(hipMemcpyAsync(d_q_, h_q_, nq * dim_ * sizeof(double), hipMemcpyHostToDevice, stream_));
     const HnswGraphView g = view();
-    VL_HIP(launch_hnsw_search(stream_, metric_, g, d_q_, (uint32_t)nq, (uint32_t)ef_walk, entry_, max_level_, d_hits_));
-    VL_HIP(hipMemcpyAsync(h_hits_, d_hits_, nq * ef_walk * sizeof(HnswHit), hipMemcpyDeviceToHost, stream_));
+    // The kernel finishes each walk the way HNSWIndex::search does (:468-495): beam in (distance, node) order,
+    // tombstones dropped, the closest max_candidates kept, distances converted to scores.  Like the reference,
+    // tombstones can make fewer than k results come back; unlike it, the slots they free are refilled from the rest
+    // of the beam when ef > k.
+    unsigned long long* d_ids = d_out_;
+    double* d_scores = reinterpret_cast<double*>(d_out_ + nq * k);
+    unsigned long long* d_n = d_out_ + 2 * nq * k;
+    VL_HIP(launch_hnsw_search(stream_, metric_, g, d_q_, (uint32_t)nq, (uint32_t)ef_walk, entry_, max_level_,
+                              (uint32_t)max_candidates, (uint32_t)k, d_ids, d_scores, d_n, d_stat_evals_));
+    VL_HIP(hipMemcpyAsync(h_out_, d_out_, nq * (2 * k + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
     VL_HIP(hipStreamSynchronize(stream_));
-
-    struct Res {
-        uint64_t id;
-        double score;
-    };
-    std::vector<Res> res;
     stat_queries_.fetch_add(nq, std::memory_order_relaxed);
+    const unsigned long long* h_n = h_out_ + 2 * nq * k;
     for (uint64_t qi = 0; qi < nq; ++qi) {
-        res.clear();
-        HnswHit* hits = h_hits_ + qi * ef_walk;
-        stat_evals_.fetch_add(hits[0].evals, std::memory_order_relaxed);
-        // The walk navigates by f32 distances and re-evaluates the final beam with the reference's f64
-        // callback (value before its `as u64`): put the beam into (distance, node) order -- a refinement of the
-        // order `neighbors` has after hnsw.nearest (:454-466), ties of the truncated value broken by the true
-        // distance -- before the closest max_candidates are taken.
-        std::sort(hits, hits + ef_walk, [](const HnswHit& a, const HnswHit& b) {
-            if ((a.node == HNSW_NONE) != (b.node == HNSW_NONE)) return b.node == HNSW_NONE;
-            return a.dist < b.dist || (a.dist == b.dist && a.node < b.node);
-        });
-        // `neighbors` holds max_candidates slots (:442-448): the walk's closest max_candidates
-        for (uint64_t i = 0; i < ef_walk && res.size() < max_candidates; ++i) {
-            const HnswHit& h = hits[i];
-            if (h.node == HNSW_NONE) break;           // :473 filters the !0 sentinels
-            if (h.node >= n_nodes_) {
-                set_last_error("HNSW walk returned an out-of-range node (kernel bug)");
-                return ERR_DEVICE;
-            }
-            if (!live_[h.node]) continue;             // :475 tombstoned nodes are dropped AFTER the walk
-            res.push_back({node_id_[h.node], hnsw_score(rust_as_u64_host(h.dist), metric_)});
-        }
-        // Note: like the reference, tombstones can make fewer than k results come back.  Unlike the
-        // reference the slots freed by tombstones are refilled from the rest of the beam when ef > k.
-        std::stable_sort(res.begin(), res.end(), [](const Res& a, const Res& b) { return a.score > b.score; });  // :493
-        const uint64_t m = std::min<uint64_t>(res.size(), k);                                                   // :494
-        for (uint64_t i = 0; i < m; ++i) {
-            out_ids[qi * k + i] = res[i].id;
-            out_scores[qi * k + i] = res[i].score;
-        }
+        const uint64_t m = std::min<uint64_t>(h_n[qi], k);
+        std::memcpy(out_ids + qi * k, h_out_ + qi * k, m * sizeof(uint64_t));
+        std::memcpy(out_scores + qi * k, h_out_ + nq * k + qi * k, m * sizeof(double));
         out_n[qi] = m;
     }
     return OK;

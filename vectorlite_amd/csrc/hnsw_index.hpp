@@ -74,7 +74,7 @@ private:
     HnswIndex(uint64_t dim, int metric, const HnswParams& p, int device);
     int ensure_graph(uint64_t nodes, uint64_t upper_slots);
     HnswGraphView view() const;
-    int ensure_search_scratch(uint64_t nq, uint32_t ef) const;
+    int ensure_search_scratch(uint64_t nq, uint64_t k) const;
     int search_exact_fallback(const double* query, uint64_t k, uint64_t* out_ids, double* out_scores, uint64_t* out_n) const;
 
     const uint64_t dim_;
@@ -113,15 +113,18 @@ private:
     std::vector<uint8_t> live_;
     uint64_t live_count_ = 0;
 
-    mutable std::atomic<uint64_t> stat_queries_{0}, stat_evals_{0};
+    mutable std::atomic<uint64_t> stat_queries_{0}, stat_evals_{0};  // stat_evals_: the exact-fallback's share only
     mutable Coalescer<CoalesceReq> co_;
 
     // search scratch
     mutable double* d_q_ = nullptr;
     mutable double* h_q_ = nullptr;
-    mutable HnswHit* d_hits_ = nullptr;
-    mutable HnswHit* h_hits_ = nullptr;
-    mutable uint64_t q_cap_ = 0, hits_cap_ = 0;
+    mutable unsigned long long* d_out_ = nullptr;  // [nq*k ids][nq*k score bits][nq counts], one D2H copy per batch
+    mutable unsigned long long* h_out_ = nullptr;  // pinned mirror
+    mutable uint64_t q_cap_ = 0, out_cap_ = 0;
+    unsigned long long* d_node_id_ = nullptr;      // [g_cap_] node -> caller's id (device copy of node_id_)
+    uint8_t* d_live_ = nullptr;                    // [g_cap_] 0 = tombstoned
+    unsigned long long* d_stat_evals_ = nullptr;   // distance evaluations of all query walks
 };
 
 }  // namespace vl
