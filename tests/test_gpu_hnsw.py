@@ -319,3 +319,15 @@ def test_duplicate_heavy_index_stays_connected(V):
         fi, fs, fn = flat.search_batch(Q, 10, metric)
         # ties everywhere: compare scores, not ids
         assert np.allclose(np.sort(1.0 / hs[:, :10] - 1.0, axis=1), np.sort(1.0 / fs - 1.0, axis=1), atol=2e-3)
+
+
+def test_no_node_is_orphaned_in_a_tiny_dense_index(V):
+    """40 nodes with M0 = 32: every list is full, late nodes get evicted from the lists they entered -- the in-degree
+    guard keeps one incoming edge per node, so ef = k = len returns every node."""
+    for seed in (429239, 1, 2, 3):
+        rng = np.random.default_rng(seed)
+        rows = np.round(rng.standard_normal((40, 4)) @ rng.standard_normal((4, 8)))
+        idx = V.HNSWIndex(8, V.SimilarityMetric.Euclidean)
+        idx.add_rows(np.arange(40, dtype=np.uint64), rows)
+        bi, bs, bn = idx.search_batch(rows[:6] + 0.05, 128, V.SimilarityMetric.Euclidean)
+        assert bn.tolist() == [40] * 6, (seed, bn.tolist())

@@ -570,6 +570,7 @@ __global__ __launch_bounds__(256) void k_hnsw_insert_search(HnswGraphView g, uin
             if ((uint32_t)lane < nsel) {
                 nb[lane] = selv;
                 nd[lane] = seld;
+                if (layer == 0) atomicAdd(&g.indeg0[selv], 1u);  // p -> selv is an incoming edge of selv
             }
             if (lane == 0) *cnt = nsel;
             if (layer > 0) next_layer(L, stamps, epoch);
@@ -604,9 +605,9 @@ __global__ __launch_bounds__(256) void k_hnsw_insert_link(HnswGraphView g, uint3
                 pnd = g.distU + (size_t)us * g.m;
                 pcnt = g.cntU[us];
             }
-            for (uint32_t t = 0; t < pcnt; ++t) {
-                const uint32_t qn = pnb[t];
-                const unsigned long long d = pnd[t];
+            // returns whether p entered qn's list (wave-uniform)
+            auto link_into = [&](uint32_t qn, unsigned long long d, bool force) -> bool {
+                bool entered = false;
                 if (lane == 0) {
                     while (atomicCAS(&g.lock[qn], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(4);
                 }
@@ -630,13 +631,17 @@ __global__ __launch_bounds__(256) void k_hnsw_insert_link(HnswGraphView g, uint3
                         qb[cq] = p;
                         qd[cq] = d;
                         __hip_atomic_store(qc, cq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (layer == 0) atomicAdd(&g.indeg0[p], 1u);
                     }
+                    entered = true;
                 } else {
-                    // farthest entry by (dist, node)
+                    // farthest entry by (dist, node) -- on layer 0 among the entries that have another incoming edge:
+                    // evicting a node's LAST incoming edge would make it unreachable for good
                     unsigned long long md = (uint32_t)lane < cap ? __hip_atomic_load(qd + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
                     uint32_t mv = (uint32_t)lane < cap ? __hip_atomic_load(qb + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                     int ml = lane;
                     if ((uint32_t)lane >= cap) ml = -1;
+                    if (layer == 0 && ml >= 0 && __hip_atomic_load(&g.indeg0[mv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 1u) ml = -1;
 #pragma unroll
                     for (int o = 32; o >= 1; o >>= 1) {
                         const unsigned long long od = __shfl_xor(md, o);
@@ -649,16 +654,37 @@ __global__ __launch_bounds__(256) void k_hnsw_insert_link(HnswGraphView g, uint3
                             ml = ol;
                         }
                     }
-                    if (d < md || (d == md && p < mv)) {
-                        if (lane == ml) {
-                            qb[lane] = p;
-                            qd[lane] = d;
+                    if (ml >= 0 && (force || d < md || (d == md && p < mv))) {  // wave-uniform after the reduction
+                        bool evict = true;
+                        if (layer == 0) {
+                            // another wave may be evicting the same node from another list right now: take the edge
+                            // away only if one remains
+                            uint32_t old = 2u;
+                            if (lane == 0) {
+                                old = atomicSub(&g.indeg0[mv], 1u);
+                                if (old <= 1u) atomicAdd(&g.indeg0[mv], 1u);
+                            }
+                            evict = (uint32_t)__builtin_amdgcn_readfirstlane((int)old) > 1u;
+                        }
+                        if (evict) {
+                            if (lane == ml) {
+                                qb[lane] = p;
+                                qd[lane] = d;
+                            }
+                            if (layer == 0 && lane == 0) atomicAdd(&g.indeg0[p], 1u);
+                            entered = true;
                         }
                     }
                 }
                 __threadfence();  // release: the list is complete before the lock opens
                 if (lane == 0) atomicExch(&g.lock[qn], 0u);
-            }
+                return entered;
+            };
+            bool any = false;
+            for (uint32_t t = 0; t < pcnt; ++t) any = link_into(pnb[t], pnd[t], false) || any;
+            // every chosen neighbour had a full list of closer entries: p would have no incoming edge at all and could
+            // never be found (seen on a 40-node index with M0 = 32) -- its nearest neighbour takes it regardless
+            if (!any && pcnt > 0) (void)link_into(pnb[0], pnd[0], true);
         }
     }
 }

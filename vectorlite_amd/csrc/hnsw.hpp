@@ -37,6 +37,7 @@ struct HnswGraphView {
     unsigned long long* distU;    // [slots, m]
     uint32_t* cntU;               // [slots]
     uint32_t* lock;               // [cap] link-phase spin locks
+    uint32_t* indeg0;             // [cap] incoming layer-0 edges of each node: an edge is never evicted when it is the target's last
     // visited stamps: one u32 per node per concurrently running wave
     uint32_t* stamps;             // [n_slots, cap]
     uint32_t* epochs;             // [n_slots]

@@ -114,7 +114,7 @@ HnswIndex::~HnswIndex()
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     void* dev[] = {d_nbr0_, d_dist0_, d_cnt0_, d_level_, d_upper_off_, d_nbrU_, d_distU_, d_cntU_,
-                   d_lock_, d_stamps_, d_epochs_, d_q_, d_out_, d_node_id_, d_live_, d_stat_evals_};
+                   d_lock_, d_indeg0_, d_stamps_, d_epochs_, d_q_, d_out_, d_node_id_, d_live_, d_stat_evals_};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     if (h_q_) (void)hipHostFree(h_q_);
@@ -147,6 +147,7 @@ HnswGraphView HnswIndex::view() const
     g.distU = d_distU_;
     g.cntU = d_cntU_;
     g.lock = d_lock_;
+    g.indeg0 = d_indeg0_;
     g.stamps = d_stamps_;
     g.epochs = d_epochs_;
     g.n_slots = n_slots_;
@@ -170,6 +171,7 @@ int HnswIndex::ensure_graph(uint64_t nodes, uint64_t upper_slots)
         VL_TRY(regrow(&d_level_, g_cap_, nc, stream_, true));
         VL_TRY(regrow(&d_upper_off_, g_cap_, nc, stream_, true));
         VL_TRY(regrow(&d_lock_, g_cap_, nc, stream_, true));
+        VL_TRY(regrow(&d_indeg0_, g_cap_, nc, stream_, true));
         VL_TRY(regrow(&d_node_id_, g_cap_, nc, stream_, true));
         VL_TRY(regrow(&d_live_, g_cap_, nc, stream_, true));
         // visited stamps: one u32 per node per concurrently walking wave, at most ~8 GB
@@ -372,6 +374,7 @@ int HnswIndex::clone(HnswIndex** out) const
         VL_TRY(copy(c->d_nbrU_, d_nbrU_, n_upper_ * params_.m * sizeof(uint32_t)));
         VL_TRY(copy(c->d_distU_, d_distU_, n_upper_ * params_.m * sizeof(unsigned long long)));
         VL_TRY(copy(c->d_cntU_, d_cntU_, n_upper_ * sizeof(uint32_t)));
+        VL_TRY(copy(c->d_indeg0_, d_indeg0_, n_nodes_ * sizeof(uint32_t)));
         VL_TRY(copy(c->d_node_id_, d_node_id_, n_nodes_ * sizeof(unsigned long long)));
         VL_TRY(copy(c->d_live_, d_live_, n_nodes_ * sizeof(uint8_t)));
         VL_HIP(hipStreamSynchronize(c->stream_));

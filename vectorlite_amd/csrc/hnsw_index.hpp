@@ -96,6 +96,7 @@ private:
     unsigned long long* d_distU_ = nullptr;
     uint32_t* d_cntU_ = nullptr;
     uint32_t* d_lock_ = nullptr;
+    uint32_t* d_indeg0_ = nullptr;
     uint32_t* d_stamps_ = nullptr;
     uint32_t* d_epochs_ = nullptr;
     uint64_t g_cap_ = 0, u_cap_ = 0;
