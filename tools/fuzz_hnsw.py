@@ -28,7 +28,18 @@ while time.time() < t_end:
         rows = np.round(rows)  # many exact ties
     ids = rng.permutation(n).astype(np.uint64) * np.uint64(7) + np.uint64(3)
     idx = V.HNSWIndex(dim, m)
-    idx.add_rows(ids, rows)
+    # ingest in 1-4 bulk calls, the tail one vector at a time, sometimes through a clone
+    cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, size=int(rng.integers(0, 4)))]))
+    tail = int(rng.integers(0, min(n, 6) + 1))
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        b2 = min(b, n - tail)
+        if b2 > a:
+            idx.add_rows(ids[a:b2], rows[a:b2])
+        if rng.random() < 0.15:
+            idx = idx.clone()
+    for j in range(n - tail, n):
+        idx.add(V.Vector(int(ids[j]), rows[j]))
+    assert len(idx) == n
     dead = set()
     if n > 10 and rng.random() < 0.5:
         for j in rng.choice(n, size=max(1, n // 20), replace=False):
