@@ -119,7 +119,6 @@ private:
 
     // search scratch
     mutable double* d_q_ = nullptr;
-    mutable double* h_q_ = nullptr;
     mutable unsigned long long* d_out_ = nullptr;  // [nq*k ids][nq*k score bits][nq counts], one D2H copy per batch
     mutable unsigned long long* h_out_ = nullptr;  // pinned mirror
     mutable uint64_t q_cap_ = 0, out_cap_ = 0;
