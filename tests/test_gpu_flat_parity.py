@@ -400,7 +400,7 @@ def test_mfma_large_batch_parity(V, O, dim, n):
     gpu.search_batch(Q, 10, 0)
     gpu.profile_enable(False)
     passes = gpu.profile_read()[0]
-    if n >= 8192 and dim != 100:  # dim 100 pads to 112 bf16 columns: no MFMA shape
+    if n >= 8192:  # dim 100 included: its bf16 rows are padded to the 128-column MFMA shape
         assert passes <= 1 + 24, passes  # the MFMA pass + the few queries it cannot certify (ties, out-of-domain), one by one
     else:
         assert passes == 19 if dim != 100 else nq - 2 <= passes <= nq, passes  # dim 100 has no 8-query f32 shape: one by one (the out-of-domain query skips the scan)

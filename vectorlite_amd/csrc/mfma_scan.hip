@@ -456,8 +456,11 @@ __global__ __launch_bounds__(256) void k_scan_bf16(const u32x4* __restrict__ sla
 
 // T_q = the 64th largest group maximum (a lower bound of the query's 64th best key); -inf when fewer
 // than 64 groups exist.  One wave per query.
+// A query of norm 0 (a zero query, or one the host zeroed because it is outside the fast-path domain) scores 0 on every
+// row: every row would be a candidate and its wave's ring segment would overflow, taking the workgroup's other 255
+// queries down with it.  It gets T_q = +inf -- no candidates at all; the host answers it on the exact path anyway.
 __global__ __launch_bounds__(256) void k_thresholds(const int* __restrict__ gmax, uint32_t n_groups, uint32_t nq,
-                                                    float* __restrict__ thr)
+                                                    const double* __restrict__ q_norms, float* __restrict__ thr)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(256) void k_thresholds(const int* __restrict__ gmax
     // lane 63 holds the 64th largest (or the sentinel when there are fewer than 64 finite maxima)
     const float t = read_lane(L.key, 63);
     const uint32_t p = read_lane(L.pos, 63);
-    if (lane == 0) thr[q] = (p == POS_SENTINEL) ? -INFINITY : t;
+    if (lane == 0) thr[q] = (q_norms[q] == 0.0) ? INFINITY : ((p == POS_SENTINEL) ? -INFINITY : t);
 }
 
 // Per query: top-64 of its candidate buffer by (key desc, position asc) -> one sorted list.
@@ -689,7 +692,8 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
         hipLaunchKernelGGL((k_mfma_scan<K, 0, MET, NW, QTT>), grid0, dim3(NW * 64), 0, s, slab, row_norm, row_sqnorm, q16, nq,       \
                            sample_tiles, (uint32_t)sample_rows, w.gmax, n_groups, (const float*)nullptr,               \
                            (Cand32*)nullptr, (uint32_t*)nullptr, 0u, 0u);                                               \
-        hipLaunchKernelGGL(k_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.gmax, n_groups, nq, w.thr);             \
+        hipLaunchKernelGGL(k_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.gmax, n_groups, nq,                     \
+                           q64 + (size_t)nq * dim, w.thr);                                                             \
         for (int st = 0; st < n_stages; ++st) {                                                                         \
             const uint32_t tb = stage_end[st], te = stage_end[st + 1];                                                  \
             const dim3 grid1((uint32_t)std::min<uint32_t>(te - tb, (uint32_t)pass1_blocks), nq_pad / qpb);              \

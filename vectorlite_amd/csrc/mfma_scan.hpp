@@ -21,7 +21,16 @@ constexpr int MFMA_MIN_BATCH = 2;      // measured at N = 10 M x 384: one bf16 p
                                        // row lengths without an MFMA shape, and as the fallback)
 
 // bf16 slab row stride in elements: dim rounded up to the MFMA K step (16)
-inline uint32_t mfma_ldb(uint32_t dim) { return (dim + 15u) & ~15u; }
+// Row stride of the bf16 slab in elements: the next length the MFMA kernel has a shape for (8 / 16 / 24 / 32 / 48
+// K steps of 16), zero padded -- a 100- or 300-dimensional index takes the batch filter too, at the price of the
+// padding; beyond 768 dimensions there is no shape and the stride is just the dimension rounded up to 16.
+inline uint32_t mfma_ldb(uint32_t dim)
+{
+    const uint32_t shapes[] = {128u, 256u, 384u, 512u, 768u};
+    for (uint32_t s : shapes)
+        if (dim <= s) return s;
+    return (dim + 15u) & ~15u;
+}
 
 struct MfmaScratch {
     void* q_bf16 = nullptr;     // [nq_cap_pad, ldb] bf16
@@ -42,6 +51,7 @@ hipError_t launch_rows_bf16(hipStream_t s, const double* master, uint64_t n, uin
 // nq queries (f64 [nq, dim]) against the bf16 slab: writes one sorted top-64 candidate list per query
 // (out_lists[nq][64], the layout k_merge_finalize takes with n_lists = 1).
 // row_norm / row_sqnorm: the arrays launch_rows_bf16 wrote (dot and Euclidean keys need them).
+// q64: [nq, dim] f64 queries followed by their [nq] f64 norms (0 = answer on the exact path: no candidates are collected).
 hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf16, const float* row_norm,
                                   const float* row_sqnorm,
                                   const double* q64, uint32_t nq, uint64_t n_rows, uint32_t dim,
