@@ -180,9 +180,6 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
     // Ring flush: the only global atomics of the kernel.  It runs at trip boundaries (where hipcc
     // drains vmcnt anyway) when the ring is half full, and once after the loop.
     auto flush_ring = [&]() {  // caller has published wave_cnt[] and passed a barrier
-        bool overflow = false;
-#pragma unroll
-        for (int w = 0; w < NWAVES; ++w) overflow = overflow || wave_cnt[w] > (uint32_t)SEG;
         for (uint32_t e = tid; e < (uint32_t)(NWAVES * SEG); e += NT) {
             const uint32_t w = e / SEG, i = e % SEG;
             if (i < wave_cnt[w]) {
@@ -196,7 +193,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
                 }
             }
         }
-        if (overflow && tid < MF_QPB) {  // a segment overflowed: these queries are redone by the host
+        // a wave whose segment overflowed lost candidates of ITS 32 QT queries only: those are redone by the host
+        if (tid < MF_QPB && wave_cnt[tid / (32 * QT)] > (uint32_t)SEG) {
             const uint32_t qq = blockIdx.y * MF_QPB + tid;
             if (qq < nq) atomicAdd(&cnt[qq], cap + 1u);
         }
