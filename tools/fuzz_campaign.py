@@ -42,12 +42,17 @@ while time.time() < t_end:
     gpu = V.FlatIndex(dim); gpu.add_rows(ids, rows, validate=False)
     ref = O.FlatOracle(dim, ids, rows)
     nq = int(rng.choice([1, 2, 5, 9, 33]))
+    if n >= 9000 and dim <= 128 and rng.random() < 0.5:
+        nq = int(rng.choice([64, 150, 300]))  # big batches on the MFMA filter, with hostile queries mixed in
     Q = rng.standard_normal((nq, dim))
     if rng.random() < 0.5:
         Q[0] = rows[rng.integers(0, n)]
+    if nq >= 64:
+        for j in rng.integers(0, nq, size=6):
+            Q[j] = [rows[rng.integers(0, n)], np.zeros(dim), Q[j] * 1e30, Q[j] * 1e-30, -rows[rng.integers(0, n)]][int(rng.integers(0, 5))]
     m = int(rng.integers(0, 4))
     k = int(rng.choice([1, 10, 48, 60, 61, 100, 220, 221, 500]))
-    mode = rng.choice(["single", "batch", "bf16", "positions"])
+    mode = "batch" if nq >= 64 else rng.choice(["single", "batch", "bf16", "positions"])
     if mode == "bf16":
         gpu.set_single_filter("bf16")
     if mode == "batch":
