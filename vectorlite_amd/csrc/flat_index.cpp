@@ -536,9 +536,10 @@ int GpuFlatIndex::search_direct(const double* query, uint64_t q_len, uint64_t k,
     return rc;
 }
 
-// nq independent searches.  Groups of SCAN_BATCH_QB queries share ONE pass over the slab
-// (k_scan_batch); every query still gets its own exact rescoring, bound check and, if that fails,
-// its own exact-path run, so each row of the output is exactly what search() returns.
+// nq independent searches sharing slab passes: up to MFMA_MAX_BATCH queries per pass over the bf16 slab
+// (k_mfma_scan: cosine / dot / Euclidean, dim <= 768, >= MFMA_MIN_ROWS rows), otherwise groups of SCAN_BATCH_QB
+// queries per pass over the f32 slab (k_scan_batch).  Every query still gets its own exact rescoring, bound check
+// and, if that fails, its own single-query or exact-path run: each row of the output is exactly what search() returns.
 int GpuFlatIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_len, uint64_t k, int metric,
                                uint64_t* out_pos, uint64_t* out_ids, double* out_scores, uint64_t* out_n) const
 {
@@ -587,7 +588,7 @@ int GpuFlatIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_le
         return OK;
     }
 
-    // large cosine / dot batches: bf16 MFMA candidate filter; whatever it cannot certify is redone below
+    // two or more queries: bf16 MFMA candidate filter; whatever it cannot certify is redone below
     std::vector<uint8_t> done(nq, 0);
     const char* mf_env = getenv("VL_MFMA");
     const bool mfma_on = !(mf_env && mf_env[0] == '0');
@@ -979,7 +980,7 @@ int GpuFlatIndex::ensure_mfma_scratch(Workspace* ws) const
     return OK;
 }
 
-// Cosine / dot batches of >= MFMA_MIN_BATCH in-domain queries.  done[qi] is set for every query
+// Cosine / dot / Euclidean batches of >= MFMA_MIN_BATCH queries.  done[qi] is set for every query
 // answered here; the caller redoes the others (bound check failed, candidate overflow, ...).
 int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, uint64_t nq, uint64_t k, uint64_t k_eff,
                                     int metric, uint64_t* out_pos, uint64_t* out_ids, double* out_scores,
