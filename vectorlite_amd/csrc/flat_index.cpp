@@ -103,6 +103,55 @@ GpuFlatIndex::GpuFlatIndex(uint64_t dim, int device)
 {
 }
 
+namespace {
+// Copies a query into its staging slot and decides whether it lies in the fast-path domain (finite, |v| <= 2^40,
+// norm 0 or >= 2^-40).  The norm only feeds the error bound and that domain test (the kernels recompute every score
+// from the values), so it is summed with four partial accumulators the compiler can vectorise; a query outside the
+// domain is staged as zeros (keeps the f32 / bf16 scans finite) with norm 0 and answered on the exact path.
+bool stage_query(const double* q, double* dst, uint64_t dim, double* norm_out)
+{
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+    uint64_t i = 0;
+    for (; i + 4 <= dim; i += 4) {
+        const double a = q[i], b = q[i + 1], c = q[i + 2], d = q[i + 3];
+        dst[i] = a;
+        dst[i + 1] = b;
+        dst[i + 2] = c;
+        dst[i + 3] = d;
+        s0 += a * a;
+        s1 += b * b;
+        s2 += c * c;
+        s3 += d * d;
+        const double fa = std::fabs(a), fb = std::fabs(b), fc = std::fabs(c), fd = std::fabs(d);
+        m0 = fa > m0 ? fa : m0;
+        m1 = fb > m1 ? fb : m1;
+        m2 = fc > m2 ? fc : m2;
+        m3 = fd > m3 ? fd : m3;
+    }
+    for (; i < dim; ++i) {
+        const double a = q[i];
+        dst[i] = a;
+        s0 += a * a;
+        const double fa = std::fabs(a);
+        m0 = fa > m0 ? fa : m0;
+    }
+    const double qq = (s0 + s1) + (s2 + s3);
+    const double m01 = m0 > m1 ? m0 : m1, m23 = m2 > m3 ? m2 : m3;
+    const double qmax = m01 > m23 ? m01 : m23;
+    const double norm = std::sqrt(qq);
+    // a NaN component makes qq NaN (the max ignores it); an infinity shows up in qmax (and qq)
+    const bool finite = qq == qq && qmax <= 1.797693134862315708e308 && norm <= 1.797693134862315708e308;
+    const bool in_domain = finite && qmax <= DOMAIN_MAX_ABS && (norm == 0.0 || norm >= DOMAIN_MIN_NORM);
+    if (!in_domain) {
+        for (uint64_t j = 0; j < dim; ++j) dst[j] = 0.0;
+        *norm_out = 0.0;
+    } else {
+        *norm_out = norm;
+    }
+    return in_domain;
+}
+}  // namespace
+
 int GpuFlatIndex::create(uint64_t dim, int device, GpuFlatIndex** out)
 {
     if (!out) return ERR_INVALID_ARG;
@@ -618,25 +667,8 @@ int GpuFlatIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_le
         const uint32_t g = (uint32_t)std::min<uint64_t>(SCAN_BATCH_QB, nq - q0);
         bool in_domain[SCAN_BATCH_QB];
         double* norms = ws->h_q64 + (size_t)g * dim_;
-        for (uint32_t j = 0; j < g; ++j) {
-            const double* q = queries + (q0 + j) * dim_;
-            double qq = 0.0, qmax = 0.0;
-            bool finite = true;
-            for (uint64_t i = 0; i < dim_; ++i) {
-                const double v = q[i];
-                ws->h_q64[(size_t)j * dim_ + i] = v;
-                qq += v * v;
-                const double av = std::fabs(v);
-                if (!(av <= 1.797693134862315708e308)) finite = false;
-                if (av > qmax) qmax = av;
-            }
-            norms[j] = std::sqrt(qq);
-            in_domain[j] = finite && qmax <= DOMAIN_MAX_ABS && (norms[j] == 0.0 || norms[j] >= DOMAIN_MIN_NORM);
-            if (!in_domain[j]) {  // keeps the f32 scan finite; this query is redone on the exact path
-                for (uint64_t i = 0; i < dim_; ++i) ws->h_q64[(size_t)j * dim_ + i] = 0.0;
-                norms[j] = 0.0;
-            }
-        }
+        for (uint32_t j = 0; j < g; ++j)
+            in_domain[j] = stage_query(queries + (q0 + j) * dim_, ws->h_q64 + (size_t)j * dim_, dim_, &norms[j]);
         VL_HIP(hipMemcpyAsync(ws->d_q64, ws->h_q64, ((size_t)g * dim_ + g) * sizeof(double), hipMemcpyHostToDevice, st));
         ScanPlan plan;
         if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
@@ -997,26 +1029,8 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, uint64
         const uint32_t g = (uint32_t)std::min<uint64_t>(MFMA_MAX_BATCH, nq - q0);
         double* norms = ws->mf_h_q64 + (size_t)g * dim_;
         std::vector<uint8_t> in_domain(g);
-        for (uint32_t j = 0; j < g; ++j) {
-            const double* q = queries + (q0 + j) * dim_;
-            double qq = 0.0, qmax = 0.0;
-            bool finite = true;
-            double* dst = ws->mf_h_q64 + (size_t)j * dim_;
-            for (uint64_t i = 0; i < dim_; ++i) {
-                const double v = q[i];
-                dst[i] = v;
-                qq += v * v;
-                const double av = std::fabs(v);
-                if (!(av <= 1.797693134862315708e308)) finite = false;
-                if (av > qmax) qmax = av;
-            }
-            norms[j] = std::sqrt(qq);
-            in_domain[j] = finite && qmax <= DOMAIN_MAX_ABS && (norms[j] == 0.0 || norms[j] >= DOMAIN_MIN_NORM);
-            if (!in_domain[j]) {
-                for (uint64_t i = 0; i < dim_; ++i) dst[i] = 0.0;
-                norms[j] = 0.0;
-            }
-        }
+        for (uint32_t j = 0; j < g; ++j)
+            in_domain[j] = stage_query(queries + (q0 + j) * dim_, ws->mf_h_q64 + (size_t)j * dim_, dim_, &norms[j]) ? 1 : 0;
         VL_HIP(hipMemcpyAsync(ws->mf_d_q64, ws->mf_h_q64, ((size_t)g * dim_ + g) * sizeof(double), hipMemcpyHostToDevice, st));
         if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
         VL_HIP(launch_mfma_candidates(st, metric, d_slab16_, d_norm16_, d_sqnorm_, ws->mf_d_q64, g, n, (uint32_t)dim_,
