@@ -113,6 +113,15 @@ int vl_index_add(vl_index *h, uint64_t id, const double *values, uint64_t len);
 int vl_index_add_bulk(vl_index *h, const uint64_t *ids, const double *values, uint64_t n, int validate,
                       int values_on_device);
 
+/* NEW -- the ingest step in front of add (src/embeddings.rs:169-181): `embeddings` is [n, dim] f32 as the model
+ * emits it (host pointer, or a device pointer on the index's device when embeddings_on_device != 0).  Each value
+ * is widened to f64 (`x as f64`, :172) and, with normalize != 0, the row is L2-normalised on the device with the
+ * host's arithmetic (:175-179: norm = sqrt of the in-order sum of squares; x / norm when norm > 0, else the row
+ * unchanged), bit for bit.  The rows are then appended like vl_index_add_bulk (same `validate` meaning and
+ * duplicate-id behaviour; HNSW handles always validate).  PCIe carries 4 bytes per value instead of 8. */
+int vl_index_add_embeddings_f32(vl_index *h, const uint64_t *ids, const float *embeddings, uint64_t n, int normalize,
+                                int validate, int embeddings_on_device);
+
 /* delete(id): removes every row with that id, order-preserving; VL_OK even when
  * the id is absent (src/index/flat.rs:93-96). */
 int vl_index_delete(vl_index *h, uint64_t id);

@@ -33,6 +33,7 @@ extern "C" {
     fn vl_index_destroy(h: *mut vl_index);
     fn vl_index_add(h: *mut vl_index, id: u64, values: *const f64, len: u64) -> c_int;
     fn vl_index_add_bulk(h: *mut vl_index, ids: *const u64, values: *const f64, n: u64, validate: c_int, values_on_device: c_int) -> c_int;
+    fn vl_index_add_embeddings_f32(h: *mut vl_index, ids: *const u64, embeddings: *const f32, n: u64, normalize: c_int, validate: c_int, embeddings_on_device: c_int) -> c_int;
     fn vl_index_delete(h: *mut vl_index, id: u64) -> c_int;
     fn vl_index_search(h: *const vl_index, query: *const f64, q_len: u64, k: u64, metric: c_int, out_ids: *mut u64, out_scores: *mut f64, out_n: *mut u64) -> c_int;
     fn vl_index_len(h: *const vl_index) -> u64;
@@ -188,6 +189,20 @@ impl GpuFlatIndex {
 }
 
 impl GpuFlatIndex {
+    /// The ingest step of `Collection::add_text` for a batch (`src/client.rs:313-345`): the embedding model's raw
+    /// f32 outputs are widened and L2-normalised on the device exactly as `EmbeddingGenerator::generate_embedding`
+    /// does on the host (`src/embeddings.rs:169-181`), then added row by row.  `texts[i]` / `metadata[i]` stay here.
+    pub fn add_embeddings(&mut self, ids: &[u64], embeddings_f32: &[f32], texts: Vec<String>, metadata: Vec<Option<serde_json::Value>>) -> Result<(), String> {
+        assert_eq!(embeddings_f32.len(), ids.len() * self.0.dim);
+        let before = self.0.len();
+        let rc = unsafe { vl_index_add_embeddings_f32(self.0.raw, ids.as_ptr(), embeddings_f32.as_ptr(), ids.len() as u64, 1, 1, 0) };
+        let taken = self.0.len() - before; // rows in front of a duplicate id are kept, like sequential add() calls
+        for ((id, t), m) in ids.iter().zip(texts).zip(metadata).take(taken) {
+            self.0.side.insert(*id, (t, m));
+        }
+        if rc == VL_OK { Ok(()) } else { Err(last_error()) }
+    }
+
     /// nq independent searches sharing slab passes (no reference counterpart); row i is exactly `search(queries[i])`.
     pub fn search_batch(&self, queries: &[f64], nq: usize, k: usize, metric: SimilarityMetric) -> VectorLiteResult<Vec<Vec<(u64, f64)>>> {
         let dim = self.0.dim;

@@ -61,6 +61,8 @@ def lib() -> C.CDLL:
         L.vlo_convert_distance_to_similarity.argtypes = [C.c_double, C.c_int]
         L.vlo_hnsw_score.restype = C.c_double
         L.vlo_hnsw_score.argtypes = [C.c_uint64, C.c_int]
+        L.vlo_embed_f32.restype = None
+        L.vlo_embed_f32.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_int, dp]
         L.vlo_flat_new.restype = C.c_void_p
         L.vlo_flat_new.argtypes = [C.c_size_t, u64p, dp, C.c_size_t]
         L.vlo_flat_free.restype = None
@@ -121,6 +123,18 @@ def hnsw_postprocess(ids, dists, k: int, metric: int) -> Tuple[np.ndarray, np.nd
     scores = np.empty(max(ids.size, 1), dtype=np.float64)
     m = lib().vlo_hnsw_postprocess(_u64p(ids), _u64p(dists), _dp(scores), ids.size, k, metric)
     return ids[:m].copy(), scores[:m].copy()
+
+
+def embed_f32(emb, normalize: bool = True) -> np.ndarray:
+    """EmbeddingGenerator's post-processing (src/embeddings.rs:169-181) of [n, dim] (or [dim]) f32 model output."""
+    e = np.ascontiguousarray(np.asarray(emb, dtype=np.float32))
+    rows = e.reshape(-1, e.shape[-1]) if e.ndim > 1 else e.reshape(1, -1)
+    out = np.empty(rows.shape, dtype=np.float64)
+    L = lib()
+    for i in range(rows.shape[0]):
+        L.vlo_embed_f32(rows[i].ctypes.data_as(C.POINTER(C.c_float)), rows.shape[1], 1 if normalize else 0,
+                        out[i].ctypes.data_as(C.POINTER(C.c_double)))
+    return out.reshape(e.shape)
 
 
 class OracleError(Exception):

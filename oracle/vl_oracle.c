@@ -80,6 +80,23 @@ double vlo_calculate(int metric, const double *a, const double *b, size_t n)
 }
 
 /* ------------------------------------------------------------------------
+ * Ingest step (src/embeddings.rs:169-181): what EmbeddingGenerator does to the
+ * model's f32 output before the row reaches FlatIndex::add
+ * ---------------------------------------------------------------------- */
+void vlo_embed_f32(const float *emb, size_t n, int normalize, double *out)
+{
+    double s = VLO_SUM_IDENTITY;
+    for (size_t i = 0; i < n; ++i) {
+        out[i] = (double)emb[i]; /* :172 `x as f64` */
+        s += out[i] * out[i];    /* :175 map(x * x).sum() */
+    }
+    const double norm = sqrt(s);
+    if (normalize && norm > 0.0) /* :176-180 */
+        for (size_t i = 0; i < n; ++i)
+            out[i] = out[i] / norm;
+}
+
+/* ------------------------------------------------------------------------
  * HNSW boundary (src/index/hnsw.rs)
  * ---------------------------------------------------------------------- */
 

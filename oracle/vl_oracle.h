@@ -47,6 +47,11 @@ double vlo_manhattan(const double *a, const double *b, size_t n);  /* src/lib.rs
 double vlo_dot(const double *a, const double *b, size_t n);        /* src/lib.rs:565-572 */
 double vlo_calculate(int metric, const double *a, const double *b, size_t n); /* src/lib.rs:380-391 */
 
+/* ---- ingest step: src/embeddings.rs:169-181 -------------------------------- */
+/* f32 model output -> stored row: `x as f64` (:172); norm = sqrt(sum of x*x) (:175);
+ * x / norm if norm > 0, else the widened values unchanged (:176-180).  normalize == 0: widen only. */
+void vlo_embed_f32(const float *emb, size_t n, int normalize, double *out);
+
 /* ---- HNSW boundary: src/index/hnsw.rs ----------------------------------- */
 /* impl Metric<Vec<f64>> for {Euclidean,Cosine,Manhattan,DotProduct}: :113-174 */
 uint64_t vlo_hnsw_distance(int metric, const double *a, const double *b, size_t n);

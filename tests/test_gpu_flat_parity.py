@@ -921,3 +921,65 @@ def test_concurrent_writers_and_coalesced_readers_do_not_deadlock_or_corrupt(V, 
     q = unit_rows(rng, 1, dim)[0]
     for m in range(4):
         assert_same(V, gpu.search_arrays(q, 10, m), ref.search(q, 10, m), m)
+
+
+def _embedding_cases(rng):
+    for n, dim in [(1, 1), (5, 3), (63, 100), (64, 64), (65, 65), (257, 384), (130, 1000)]:
+        e = rng.standard_normal((n, dim)).astype(np.float32)
+        if n > 4:
+            e[2] = 0.0                       # norm == 0: left as it is (src/embeddings.rs:176-180)
+            e[3] *= np.float32(1e-30)        # squares far below f32 range, fine in f64
+            e[4] *= np.float32(1e30)
+        yield n, dim, e
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+def test_embedding_ingest_is_bit_identical_to_host_postprocessing(V, O, normalize):
+    """vl_index_add_embeddings_f32: widening + L2 normalisation on the device equals
+    src/embeddings.rs:169-181 bit for bit, from host arrays and from device tensors."""
+    import torch
+    rng = np.random.default_rng(77)
+    for n, dim, e in _embedding_cases(rng):
+        want = O.embed_f32(e, normalize=normalize).reshape(n, dim)
+        ids = permuted_ids(n)
+        for src in ("host", "device"):
+            idx = V.FlatIndex(dim)
+            idx.add_embeddings(ids, e if src == "host" else torch.from_numpy(e).cuda(), normalize=normalize)
+            got_ids, got = idx.export()
+            assert got_ids.tolist() == ids.tolist()
+            assert np.array_equal(got.reshape(n, dim).view(np.uint64), want.view(np.uint64)), (n, dim, src)
+        # searching the ingested rows == searching an index built from the host-normalised rows
+        ref = V.FlatIndex(dim)
+        ref.add_rows(ids, want)
+        q = rng.standard_normal(dim)
+        for m in M.values():
+            a, b = idx.search_arrays(q, 7, m), ref.search_arrays(q, 7, m)
+            assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist()
+
+
+def test_embedding_ingest_chunks_duplicates_and_hnsw(V, O):
+    rng = np.random.default_rng(78)
+    # more rows than one 512 MB chunk of f64 rows holds at this width: 2 chunks
+    dim, n = 3072, 25000
+    e = rng.standard_normal((n, dim)).astype(np.float32)
+    idx = V.FlatIndex(dim)
+    idx.add_embeddings(np.arange(n, dtype=np.uint64), e)
+    assert len(idx) == n
+    for r in (0, 21844, 21845, 21846, n - 1):
+        assert idx.get_vector(r).values == O.embed_f32(e[r]).tolist()
+    # n sequential add() calls: rows in front of the first duplicate id stay (src/index/flat.rs:86-88)
+    small = V.FlatIndex(4)
+    em = rng.standard_normal((6, 4)).astype(np.float32)
+    with pytest.raises(V.IndexOpError, match="already exists"):
+        small.add_embeddings([1, 2, 3, 2, 5, 6], em)
+    assert len(small) == 3 and small.get_vector(3).values == O.embed_f32(em[2]).tolist()
+    # HNSW handles take the same entry point (always validating)
+    h = V.HNSWIndex(16, V.SimilarityMetric.Cosine)
+    eh = rng.standard_normal((300, 16)).astype(np.float32)
+    h.add_embeddings(np.arange(300, dtype=np.uint64), eh)
+    assert len(h) == 300 and h.get_vector(17).values == O.embed_f32(eh[17]).tolist()
+    res = h.search(O.embed_f32(eh[17]).tolist(), 1, V.SimilarityMetric.Cosine)
+    assert res[0].id == 17
+    with pytest.raises(V.IndexOpError, match="already exists"):
+        h.add_embeddings([1000, 17], eh[:2])
+    assert len(h) == 301

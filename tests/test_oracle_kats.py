@@ -176,3 +176,26 @@ def test_sum_identity_sign():
     s = O.calculate(O.DOT, [0.0, 0.0], [-1.0, -2.0])
     assert s == 0.0 and math.copysign(1.0, s) == -1.0
     assert math.copysign(1.0, O.calculate(O.DOT, [0.0], [1.0])) == 1.0
+
+
+def test_embedding_postprocessing_restatement():
+    # src/embeddings.rs:169-181; the reference's own check is |norm - 1| < 1e-10 (src/embeddings.rs:374-383)
+    assert O.embed_f32(np.array([3, 4], dtype=np.float32)).tolist() == [0.6, 0.8]
+    assert O.embed_f32(np.array([3, 4], dtype=np.float32), normalize=False).tolist() == [3.0, 4.0]
+    z = O.embed_f32(np.zeros(5, dtype=np.float32))
+    assert z.tolist() == [0.0] * 5  # norm == 0: the row is left as it is
+    rng = np.random.default_rng(3)
+    for dim in (1, 7, 64, 384, 1000):
+        e = rng.standard_normal((6, dim)).astype(np.float32)
+        out = O.embed_f32(e)
+        for r in range(6):
+            w = [float(x) for x in e[r]]  # `x as f64`
+            s = -0.0
+            for x in w:
+                s += x * x
+            norm = math.sqrt(s)
+            assert out[r].tolist() == [x / norm for x in w]
+            chk = -0.0
+            for x in out[r].tolist():
+                chk += x * x
+            assert abs(math.sqrt(chk) - 1.0) < 1e-10

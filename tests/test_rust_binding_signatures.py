@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 RUST_TO_C = {
     "u64": "uint64_t", "u32": "uint32_t", "c_int": "int", "f64": "double",
-    "*const f64": "const double *", "*mut f64": "double *",
+    "*const f64": "const double *", "*mut f64": "double *", "*const f32": "const float *",
     "*const u64": "const uint64_t *", "*mut u64": "uint64_t *",
     "*const vl_index": "const vl_index *", "*mut vl_index": "vl_index *", "*mut *mut vl_index": "vl_index **",
     "*const c_char": "const char *", "": "void",

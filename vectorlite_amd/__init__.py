@@ -146,6 +146,34 @@ def _pu64(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_uint64))
 
 
+def _add_embeddings(L, h, dim: int, ids, embeddings, normalize: bool, validate: bool) -> None:
+    """vl_index_add_embeddings_f32: [n, dim] f32 numpy array or torch tensor (a CUDA/HIP tensor on the index's
+    device is read in place); widened and L2-normalised on the device as src/embeddings.rs:171-179 does."""
+    ids = np.ascontiguousarray(np.asarray(ids, dtype=np.uint64))
+    on_device = False
+    try:
+        import torch
+        is_tensor = isinstance(embeddings, torch.Tensor)
+    except Exception:  # pragma: no cover
+        is_tensor = False
+    if is_tensor and embeddings.is_cuda:
+        import torch
+        if embeddings.dtype != torch.float32 or not embeddings.is_contiguous():
+            raise ValueError("device embeddings must be a contiguous float32 tensor")
+        torch.cuda.current_stream(embeddings.device).synchronize()  # producer kernels are done
+        ptr, count, on_device = C.c_void_p(embeddings.data_ptr()), embeddings.numel(), True
+    else:
+        emb = np.ascontiguousarray(np.asarray(embeddings.numpy() if is_tensor else embeddings, dtype=np.float32))
+        ptr, count = C.c_void_p(emb.ctypes.data), emb.size
+    if count != ids.size * dim:
+        raise ValueError("embeddings must be [n, dim]")
+    rc = L.vl_index_add_embeddings_f32(h, _pu64(ids), ptr, ids.size, 1 if normalize else 0, 1 if validate else 0,
+                                       1 if on_device else 0)
+    if rc == VL_ERR_DUP_ID:
+        raise IndexOpError(_last_error())
+    _raise(rc)
+
+
 class FlatIndex:
     """GPU-resident counterpart of `FlatIndex` (src/index/flat.rs:60-135).
 
@@ -316,6 +344,11 @@ class FlatIndex:
             raise IndexOpError(_last_error())
         _raise(rc)
 
+    def add_embeddings(self, ids, embeddings, normalize: bool = True, validate: bool = True) -> None:
+        """The ingest step in front of add (src/embeddings.rs:169-181 then src/index/flat.rs:82-91 per row): f32
+        model output -> normalised f64 rows on the device -> n x add()."""
+        _add_embeddings(self._L, self._h, self.dimension(), ids, embeddings, normalize, validate)
+
     def reserve(self, n_rows: int) -> None:
         _raise(self._L.vl_index_reserve(self._h, int(n_rows)))
 
@@ -465,6 +498,10 @@ class HNSWIndex:
         if rc == VL_ERR_DUP_ID:
             raise IndexOpError(_last_error())
         _raise(rc)
+
+    def add_embeddings(self, ids, embeddings, normalize: bool = True) -> None:
+        """f32 model output -> normalised f64 rows on the device (src/embeddings.rs:169-181) -> n x add()."""
+        _add_embeddings(self._L, self._h, self.dimension(), ids, embeddings, normalize, True)
 
     def delete(self, id: int) -> None:
         rc = self._L.vl_index_delete(self._h, int(id))

@@ -179,6 +179,25 @@ int vl_index_add_bulk(vl_index* h, const uint64_t* ids, const double* values, ui
     });
 }
 
+int vl_index_add_embeddings_f32(vl_index* h, const uint64_t* ids, const float* embeddings, uint64_t n, int normalize,
+                                int validate, int embeddings_on_device)
+{
+    return guarded([&]() -> int {
+        if (!h) return VL_ERR_INVALID_ARG;
+        if (h->hnsw)
+            return vl::add_embeddings_f32(h->hnsw->device(), h->hnsw->dimension(), ids, embeddings, n, normalize != 0,
+                                          embeddings_on_device != 0,
+                                          [&](const uint64_t* i, const double* rows, uint64_t c) {
+                                              return h->hnsw->add_bulk(i, rows, c, true);
+                                          });
+        return vl::add_embeddings_f32(h->flat->device(), h->flat->dimension(), ids, embeddings, n, normalize != 0,
+                                      embeddings_on_device != 0,
+                                      [&](const uint64_t* i, const double* rows, uint64_t c) {
+                                          return h->flat->add_bulk(i, rows, c, validate != 0, true);
+                                      });
+    });
+}
+
 int vl_index_delete(vl_index* h, uint64_t id)
 {
     return guarded([&]() -> int {

@@ -1184,4 +1184,43 @@ int GpuFlatIndex::hnsw_distances(const double* query, uint64_t q_len, int metric
     return OK;
 }
 
+// Ingest step in front of add (src/embeddings.rs:169-181): f32 embeddings are widened and
+// normalised on the device in chunks (launch_embed_f32) and handed to `append` as device-resident f64 rows, so
+// the host never holds an f64 copy and PCIe carries 4 bytes per value instead of 8.
+int add_embeddings_f32(int device, uint64_t dim, const uint64_t* ids, const float* emb, uint64_t n, bool normalize,
+                       bool emb_on_device, const std::function<int(const uint64_t*, const double*, uint64_t)>& append)
+{
+    if (n == 0) return OK;
+    if (!ids || (!emb && dim)) return ERR_INVALID_ARG;
+    VL_HIP(hipSetDevice(device));
+    const uint64_t row_bytes = std::max<uint64_t>(dim, 1) * sizeof(double);
+    const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(n, (512ull << 20) / row_bytes));
+    struct Scratch {
+        hipStream_t st = nullptr;
+        double* rows = nullptr;
+        float* staged = nullptr;
+        ~Scratch()
+        {
+            if (rows) (void)hipFree(rows);
+            if (staged) (void)hipFree(staged);
+            if (st) (void)hipStreamDestroy(st);
+        }
+    } sc;
+    VL_HIP(hipStreamCreateWithFlags(&sc.st, hipStreamNonBlocking));
+    VL_HIP(hipMalloc(&sc.rows, chunk * row_bytes));
+    if (!emb_on_device) VL_HIP(hipMalloc(&sc.staged, chunk * std::max<uint64_t>(dim, 1) * sizeof(float)));
+    for (uint64_t done = 0; done < n; done += chunk) {
+        const uint64_t c = std::min(chunk, n - done);
+        const float* src = emb + done * dim;
+        if (!emb_on_device && dim) {
+            VL_HIP(hipMemcpyAsync(sc.staged, src, c * dim * sizeof(float), hipMemcpyHostToDevice, sc.st));
+            src = sc.staged;
+        }
+        VL_HIP(launch_embed_f32(sc.st, src, c, (uint32_t)dim, normalize, sc.rows));
+        VL_HIP(hipStreamSynchronize(sc.st));
+        VL_TRY(append(ids + done, sc.rows, c));  // stops at the first duplicate id like n sequential add() calls
+    }
+    return OK;
+}
+
 }  // namespace vl

@@ -10,6 +10,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
@@ -218,5 +219,10 @@ private:
     mutable double prof_ms_ = 0.0;
     mutable uint64_t prof_bytes_ = 0;
 };
+
+// NEW: f32 embeddings [n, dim] (host or device) -> widened, optionally L2-normalised f64 rows on the
+// device with the arithmetic of src/embeddings.rs:171-179, appended through `append(ids, device rows, count)`.
+int add_embeddings_f32(int device, uint64_t dim, const uint64_t* ids, const float* emb, uint64_t n, bool normalize,
+                       bool emb_on_device, const std::function<int(const uint64_t*, const double*, uint64_t)>& append);
 
 }  // namespace vl

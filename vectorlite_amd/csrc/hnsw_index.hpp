@@ -57,6 +57,7 @@ public:
                      uint64_t* out_ids, double* out_scores, uint64_t* out_n) const;
     uint64_t len() const;
     uint64_t dimension() const { return dim_; }
+    int device() const { return device_; }
     int metric() const { return metric_; }
     int get_vector(uint64_t id, double* out) const;
     int max_id(uint64_t* out) const;

@@ -914,6 +914,55 @@ __global__ __launch_bounds__(256) void k_ingest(const double* __restrict__ maste
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Embedding ingest: the model's f32 output -> the f64 row the index stores, with the
+// arithmetic of src/embeddings.rs:171-179: x as f64; norm = sqrt(sum of x*x in index order);
+// x / norm when norm > 0, the widened values unchanged otherwise.
+// One wave owns 64 rows per trip: the rows' columns go through a padded LDS tile 64 at a time (coalesced
+// 256-byte reads), lane r then adds row r's squares in index order; the scaled rows are written
+// coalesced, each lane fetching its row's norm by shuffle.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_embed_f32(const float* __restrict__ emb, uint64_t n, uint32_t dim,
+                                                   int normalize, double* __restrict__ out)
+{
+    __shared__ float tile[4][WAVE][WAVE + 1];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint64_t n_groups = (n + WAVE - 1) / WAVE;
+    // every wave of a workgroup runs the same trips (the barriers below), rows past n are skipped
+    for (uint64_t g0 = (uint64_t)blockIdx.x * 4; g0 < n_groups; g0 += (uint64_t)gridDim.x * 4) {
+        const uint64_t base = (g0 + wave) * WAVE;
+        double ss = -0.0;  // `.sum::<f64>()` folds from -0.0
+        if (normalize) {
+            for (uint32_t c0 = 0; c0 < dim; c0 += WAVE) {
+                const uint32_t c = c0 + lane;
+                __syncthreads();
+                for (int rr = 0; rr < WAVE; ++rr) {
+                    const uint64_t row = base + rr;
+                    tile[wave][rr][lane] = (row < n && c < dim) ? emb[row * dim + c] : 0.f;
+                }
+                __syncthreads();
+                const uint32_t w = dim - c0 < (uint32_t)WAVE ? dim - c0 : (uint32_t)WAVE;
+                for (uint32_t j = 0; j < w; ++j) {
+                    const double v = (double)tile[wave][lane][j];
+                    ss += v * v;
+                }
+            }
+        }
+        const double norm = sqrt(ss);
+        const int scale = (normalize && norm > 0.0) ? 1 : 0;
+        for (int rr = 0; rr < WAVE; ++rr) {
+            const uint64_t row = base + rr;
+            if (row >= n) break;  // wave-uniform
+            const double nr = __shfl(norm, rr);
+            const int sc = __shfl(scale, rr);
+            for (uint32_t c = lane; c < dim; c += WAVE) {
+                const double v = (double)emb[row * dim + c];
+                out[row * dim + c] = sc ? v / nr : v;
+            }
+        }
+    }
+}
+
 template <typename F>
 hipError_t dispatch_metric(int metric, F&& f)
 {
@@ -937,6 +986,15 @@ int env_int(const char* name, int dflt)
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
+hipError_t launch_embed_f32(hipStream_t s, const float* emb, uint64_t n, uint32_t dim, bool normalize, double* out)
+{
+    if (n == 0 || dim == 0) return hipSuccess;
+    const uint64_t blocks = ((n + WAVE - 1) / WAVE + 3) / 4;
+    const int grid = (int)(blocks < 4096 ? blocks : 4096);
+    hipLaunchKernelGGL(k_embed_f32, dim3(grid), dim3(256), 0, s, emb, n, dim, normalize ? 1 : 0, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_ingest(hipStream_t s, const double* master, float* slab, float* inv_norm, uint8_t* flags,
                          IngestStats* stats, uint64_t n, uint32_t dim, uint32_t ld)
 {

@@ -55,6 +55,10 @@ struct ScanPlan {
     int variant;   // which instantiation ran (diagnostics)
 };
 
+// f32 embeddings [n, dim] -> f64 rows [n, dim], widened and (normalize) L2-normalised with the host arithmetic of
+// src/embeddings.rs:171-179 (sequential sum of squares, sqrt, one division per value; a zero row stays as it is).
+hipError_t launch_embed_f32(hipStream_t s, const float* emb, uint64_t n, uint32_t dim, bool normalize, double* out);
+
 // f64 master rows [n, dim] -> f32 slab rows [n, ld] (zero padded), inv_norm[n], flags[n], stats.
 hipError_t launch_ingest(hipStream_t s, const double* master, float* slab, float* inv_norm, uint8_t* flags,
                          IngestStats* stats, uint64_t n, uint32_t dim, uint32_t ld);
