@@ -56,7 +56,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [cc, f"--offload-arch={ARCH}"] + COMMON + ["-c", s, "-o", o]
+            cmd = [cc, f"--offload-arch={ARCH}"] + COMMON + os.environ.get("VL_EXTRA_CFLAGS", "").split() + ["-c", s, "-o", o]
             if src.endswith(".cpp"):
                 cmd.insert(1, "-x")
                 cmd.insert(2, "hip")

@@ -979,9 +979,11 @@ int GpuFlatIndex::ensure_bf16_slab() const
     const uint64_t n = ids_.size();
     const uint32_t ldb = mfma_ldb((uint32_t)dim_);
     if (!d_slab16_) {
-        VL_HIP(hipMalloc(&d_slab16_, cap_ * (size_t)ldb * 2));
-        VL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sqnorm_), cap_ * sizeof(float)));
-        VL_HIP(hipMalloc(reinterpret_cast<void**>(&d_norm16_), cap_ * sizeof(float)));
+        // whole MFMA tiles: k_mfma_scan reads the last, partial tile past the live rows (and masks them)
+        const size_t cap16 = (cap_ + MFMA_TILE_ROWS - 1) / MFMA_TILE_ROWS * MFMA_TILE_ROWS;
+        VL_HIP(hipMalloc(&d_slab16_, cap16 * (size_t)ldb * 2));
+        VL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sqnorm_), cap16 * sizeof(float)));
+        VL_HIP(hipMalloc(reinterpret_cast<void**>(&d_norm16_), cap16 * sizeof(float)));
         slab16_rows_ = 0;
     }
     if (slab16_rows_ < n) {

@@ -34,6 +34,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 
 constexpr int MF_ROWS = 32;  // rows per tile (MFMA M)
+static_assert(MF_ROWS == (int)MFMA_TILE_ROWS, "the slab is allocated in whole tiles of this size");
 
 // order-preserving float <-> int (for max over possibly negative keys)
 __device__ __forceinline__ int enc_f(float f)
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
     // global buffers AFTER the loop: a (rare, conditional) global atomic inside the loop would make
     // the loop's vmcnt bookkeeping path-dependent and collapse the prefetch ring to depth 1.
     constexpr int RING = (MODE == 1) ? 1024 : 1;
-    constexpr int NBUF = (2 * MF_ROWS * LDS_ROW + RING * 10 <= 64000) ? 2 : 1;  // static LDS stays under 64 KB
+    constexpr int NBUF = (2 * MF_ROWS * LDS_ROW + RING * 10 <= 150000) ? 2 : 1;  // gfx950: 160 KB of LDS per workgroup
     __shared__ __attribute__((aligned(16))) unsigned char a_lds[NBUF][MF_ROWS * LDS_ROW];
     __shared__ __attribute__((aligned(16))) float inv_lds[NBUF][MF_ROWS];  // |x|   (dot, Euclidean)
     __shared__ __attribute__((aligned(16))) float sqn_lds[NBUF][MF_ROWS];  // |x|^2 (Euclidean)
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
 
     // Register prefetch ring: DEPTH tiles are in flight per workgroup.  One workgroup per CU leaves
     // only the loop itself to hide the ~2 us HBM latency, and one tile's MFMAs cover a fraction of it.
-    constexpr int DEPTH = (CPT <= 3) ? 4 : 2;
+    constexpr int DEPTH = (CPT <= 3) ? 4 : 2;  // (a third tile in flight at dim 768 changed nothing: 3.09 vs 3.07 ms)
     u32x4 stage[DEPTH][CPT];
     float stage_inv[DEPTH], stage_sqn[DEPTH];
     // Loads are UNCONDITIONAL (addresses are clamped instead of predicated): a load under a branch
@@ -129,22 +130,19 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
     // before every use, which exposes one full HBM latency per tile.
     static_assert(CHUNKS % NT == 0, "a tile is a whole number of 16-byte pieces per thread");
     auto issue_loads = [&](uint32_t tile, u32x4(&st)[CPT], float& st_inv, float& st_sqn) {
-        const uint32_t row0 = tile * MF_ROWS;
+        // Rows are dense (ROW_BYTES = CPR * 16), so a tile is ONE contiguous block: a workgroup-uniform base plus
+        // 16 * (tid + i NT) per piece -- no per-piece row arithmetic, no clamp.  The slab is allocated in whole
+        // tiles (MFMA_TILE_ROWS), so the last, partial tile reads rows past n_rows; the epilogue masks them.
+        const unsigned char* tbase = reinterpret_cast<const unsigned char*>(slab16) + (size_t)tile * (MF_ROWS * ROW_BYTES);
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const int c = tid + i * NT;
-            uint32_t row = row0 + (uint32_t)(c / CPR);
-            row = row < n_rows ? row : n_rows - 1;  // rows past the end are masked in the epilogue
-            const unsigned char* src = reinterpret_cast<const unsigned char*>(slab16) + (size_t)row * ROW_BYTES +
-                                       (size_t)(c % CPR) * 16;
             // plain (cacheable) loads on purpose: the workgroups of the other query chunks read the same
             // tile at about the same time and are served by the XCD's L2 / the Infinity Cache
-            st[i] = *reinterpret_cast<const u32x4*>(src);
+            st[i] = *reinterpret_cast<const u32x4*>(tbase + (uint32_t)(tid + i * NT) * 16u);
         }
         // The slab rows are unit-normalised (cosine needs no per-row scalar at all); dot restores
         // x.q = (x^.q) |x|, Euclidean uses key = 2 (x^.q) |x| - |x|^2.
-        uint32_t arow_i = row0 + (uint32_t)(tid & (MF_ROWS - 1));
-        arow_i = arow_i < n_rows ? arow_i : n_rows - 1;
+        const uint32_t arow_i = tile * MF_ROWS + (uint32_t)(tid & (MF_ROWS - 1));
         st_inv = (METRIC != COSINE) ? row_nrm[arow_i] : 1.0f;
         st_sqn = (METRIC == EUCLIDEAN) ? row_sqn[arow_i] : 0.0f;
     };
