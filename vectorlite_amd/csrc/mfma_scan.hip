@@ -44,7 +44,7 @@ __device__ __forceinline__ int enc_f(float f)
 }
 __device__ __forceinline__ float dec_f(int e) { return __int_as_float(e >= 0 ? e : e ^ 0x7FFFFFFF); }
 
-template <int KSTEPS, int MODE, int METRIC, int NWAVES, int QT>
+template <int KSTEPS, int MODE, int METRIC, int NWAVES, int QT, int KSPLIT = 1>
 __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restrict__ slab16,
                                                    const float* __restrict__ row_nrm,
                                                    const float* __restrict__ row_sqn,
@@ -60,17 +60,26 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
     constexpr int LDS_ROW = ROW_BYTES + 32;
     constexpr int CHUNKS = MF_ROWS * ROW_BYTES / 16;  // 16-byte pieces per tile
     constexpr int NT = NWAVES * 64;                   // threads per workgroup
-    constexpr int MF_QPB = NWAVES * 32 * QT;          // queries per workgroup: QT 32-column MFMA tiles per wave
+    // KSPLIT = 2 (dim 768): waves w and w + QWAVES serve the SAME 32 QT queries, each over one half of K, so a wave
+    // keeps half of the query fragments (96 instead of 192 VGPRs) and two waves fit on a SIMD; the partial sums
+    // meet in LDS once per tile and each wave of the pair finishes one of the two 16-row blocks.
+    static_assert(KSPLIT == 1 || KSPLIT == 2, "K is whole or halved");
+    constexpr int QWAVES = NWAVES / KSPLIT;           // waves with distinct query tiles
+    constexpr int NRB = 2 / KSPLIT;                   // 16-row blocks a wave finishes
+    constexpr int MF_QPB = QWAVES * 32 * QT;          // queries per workgroup: QT 32-column MFMA tiles per wave
     constexpr int CPT = (CHUNKS + NT - 1) / NT;       // pieces per thread
     constexpr int CPR = ROW_BYTES / 16;               // pieces per row
     // Candidates found in the loop go to a workgroup ring in LDS and are flushed to the per-query
     // global buffers AFTER the loop: a (rare, conditional) global atomic inside the loop would make
     // the loop's vmcnt bookkeeping path-dependent and collapse the prefetch ring to depth 1.
     constexpr int RING = (MODE == 1) ? 1024 : 1;
-    constexpr int NBUF = (2 * MF_ROWS * LDS_ROW + RING * 10 <= 150000) ? 2 : 1;  // gfx950: 160 KB of LDS per workgroup
+    constexpr int XCH = (KSPLIT == 2) ? 2 * NWAVES * QT * 2 * 64 * 16 : 0;  // bytes of the partial-sum exchange
+    constexpr int NBUF = (2 * MF_ROWS * LDS_ROW + RING * 10 + XCH <= 150000) ? 2 : 1;  // gfx950: 160 KB of LDS per workgroup
     __shared__ __attribute__((aligned(16))) unsigned char a_lds[NBUF][MF_ROWS * LDS_ROW];
     __shared__ __attribute__((aligned(16))) float inv_lds[NBUF][MF_ROWS];  // |x|   (dot, Euclidean)
     __shared__ __attribute__((aligned(16))) float sqn_lds[NBUF][MF_ROWS];  // |x|^2 (Euclidean)
+    __shared__ f32x4 xch[KSPLIT == 2 ? 2 : 1][KSPLIT == 2 ? NWAVES : 1][QT][2][KSPLIT == 2 ? 64 : 1];
+    __shared__ float rm_lds[KSPLIT == 2 ? NWAVES * QT * 2 * 16 : 1];
     __shared__ float ring_key[RING];
     __shared__ uint32_t ring_pos[RING];
     __shared__ unsigned short ring_q[RING];
@@ -83,6 +92,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int qwave = wave % QWAVES, khalf = wave / QWAVES;  // query tile owner, K half (0 when KSPLIT == 1)
     // v_mfma_f32_16x16x32_bf16 (holds a higher clock than the 32x32x16 form on this chip: 1.76 vs 1.27-1.45 PF in
     // the bare fragment loop, tools/micro/mfma_loop.hip).  A wave still owns 32 rows x 32 queries per QT tile,
     // as 2 row blocks x 2 query blocks of 16: lane = (c16, kg) holds row/query c16 of its block and the 8 values
@@ -90,18 +100,21 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
     const int c16 = lane & 15, kg = lane >> 4;
     constexpr int KS32 = KSTEPS / 2;  // K = 32 per MFMA
     static_assert(KSTEPS % 2 == 0, "whole 32-deep K steps");
+    constexpr int KSW = KS32 / KSPLIT;  // K steps of this wave
+    static_assert(KS32 % KSPLIT == 0, "K halves are whole steps");
     uint32_t q[QT][2];
     bool q_valid[QT][2];
-    bf16x8 bfrag[QT][2][KS32];
+    bf16x8 bfrag[QT][2][KSW];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            q[qt][qb] = blockIdx.y * MF_QPB + (wave * QT + qt) * 32 + qb * 16 + c16;
+            q[qt][qb] = blockIdx.y * MF_QPB + (qwave * QT + qt) * 32 + qb * 16 + c16;
             q_valid[qt][qb] = q[qt][qb] < nq;
 #pragma unroll
-            for (int s = 0; s < KS32; ++s)
-                bfrag[qt][qb][s] = *reinterpret_cast<const bf16x8*>(q16 + (size_t)q[qt][qb] * LDB + 32 * s + 8 * kg);
+            for (int s = 0; s < KSW; ++s)
+                bfrag[qt][qb][s] =
+                    *reinterpret_cast<const bf16x8*>(q16 + (size_t)q[qt][qb] * LDB + 32 * (s + khalf * KSW) + 8 * kg);
         }
 
     // tile schedule: workgroup x takes tiles x, x + gridDim.x, ... in both modes, so neighbouring
@@ -175,6 +188,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
         issue_loads(pt < t_end ? pt : t_last, stage[j], stage_inv[j], stage_sqn[j]);
     }
     int buf = 0;
+    int xpar = 0;
     // Ring flush: the only global atomics of the kernel.  It runs at trip boundaries (where hipcc
     // drains vmcnt anyway) when the ring is half full, and once after the loop.
     auto flush_ring = [&]() {  // caller has published wave_cnt[] and passed a barrier
@@ -192,7 +206,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
             }
         }
         // a wave whose segment overflowed lost candidates of ITS 32 QT queries only: those are redone by the host
-        if (tid < MF_QPB && wave_cnt[tid / (32 * QT)] > (uint32_t)SEG) {
+        if (tid < MF_QPB && (wave_cnt[tid / (32 * QT)] > (uint32_t)SEG ||
+                             (KSPLIT == 2 && wave_cnt[tid / (32 * QT) + (KSPLIT - 1) * QWAVES] > (uint32_t)SEG))) {
             const uint32_t qq = blockIdx.y * MF_QPB + tid;
             if (qq < nq) atomicAdd(&cnt[qq], cap + 1u);
         }
@@ -228,10 +243,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
             // A fragments are read from LDS one GROUP ahead of the MFMAs that consume them (left alone
             // the compiler reuses one register quad and every MFMA waits out an LDS round trip); each
             // fragment feeds 2 QT MFMAs.
-            const unsigned char* arow = &a_lds[buf][c16 * LDS_ROW + kg * 16];
+            const unsigned char* arow = &a_lds[buf][c16 * LDS_ROW + kg * 16 + khalf * (KSW * 64)];
             constexpr int GS = 2;            // K = 32 steps per group: 4 fragment reads, 8 QT MFMAs of 16 cycles
-            constexpr int NG = KS32 / GS;
-            static_assert(KS32 % GS == 0, "K steps come in whole groups");
+            constexpr int NG = KSW / GS;
+            static_assert(KSW % GS == 0, "K steps come in whole groups");
             bf16x8 afrag[2][GS][2];
 #pragma unroll
             for (int jj = 0; jj < GS; ++jj)
@@ -261,6 +276,27 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
                                     afrag[g & 1][jj][rb], bfrag[qt][qb][g * GS + jj], acc[qt][rb][qb], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (KSPLIT == 2) {
+                // each wave of a pair hands over the row block the other one finishes (khalf 0 keeps rows 0-15, khalf 1
+                // rows 16-31); the slot alternates with the tile, so the barrier at the top of the next tile is all that
+                // separates this tile's reads from the writes two tiles on
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) xch[xpar][wave][qt][qb][lane] = khalf ? acc[qt][0][qb] : acc[qt][1][qb];
+                __syncthreads();
+                const int partner = khalf ? wave - QWAVES : wave + QWAVES;
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) {
+                        const f32x4 other = xch[xpar][partner][qt][qb][lane];
+                        const f32x4 mine = khalf ? acc[qt][1][qb] : acc[qt][0][qb];
+                        acc[qt][0][qb] = mine + other;
+                    }
+                xpar ^= 1;
+            }
+            const int rbase = (KSPLIT == 2) ? 16 * khalf : 0;  // first row of the block(s) this wave finishes
             // C layout of a 16x16 block: column = lane & 15 (query), row = 4 (lane >> 4) + reg.
             // Epilogue on the common path = the key arithmetic, a max tree and ONE compare per query
             // against its threshold; the per-row work only runs for the rare tile that holds a candidate.
@@ -268,34 +304,34 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
             f32x4 aux[2], aux2[2];
             if (METRIC != COSINE) {
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb) aux[rb] = *reinterpret_cast<const f32x4*>(&inv_lds[buf][16 * rb + 4 * kg]);
+                for (int rb = 0; rb < NRB; ++rb) aux[rb] = *reinterpret_cast<const f32x4*>(&inv_lds[buf][rbase + 16 * rb + 4 * kg]);
             }
             if (METRIC == EUCLIDEAN) {
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb) aux2[rb] = *reinterpret_cast<const f32x4*>(&sqn_lds[buf][16 * rb + 4 * kg]);
+                for (int rb = 0; rb < NRB; ++rb) aux2[rb] = *reinterpret_cast<const f32x4*>(&sqn_lds[buf][rbase + 16 * rb + 4 * kg]);
             }
             const bool partial = row0 + MF_ROWS > n_rows || !tile_live;  // partial last tile / repeated tail tile (wave-uniform)
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
-                    float keys[8];  // rows 16 rb + 4 kg + jj
+                    float keys[4 * NRB];  // rows rbase + 16 rb + 4 kg + jj
 #pragma unroll
-                    for (int rb = 0; rb < 2; ++rb) {
+                    for (int rb = 0; rb < NRB; ++rb) {
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) {
                             float key = acc[qt][rb][qb][jj];                                       // cosine: x^.q
                             if (METRIC == DOT) key *= aux[rb][jj];                                 // x.q
                             if (METRIC == EUCLIDEAN) key = 2.0f * key * aux[rb][jj] - aux2[rb][jj];  // |q|^2 - |x - q|^2
-                            if (partial && (!tile_live || row0 + (uint32_t)(16 * rb + 4 * kg + jj) >= n_rows)) key = -INFINITY;
+                            if (partial && (!tile_live || row0 + (uint32_t)(rbase + 16 * rb + 4 * kg + jj) >= n_rows)) key = -INFINITY;
                             keys[4 * rb + jj] = key;
                         }
                     }
-                    float m2[2];
+                    float m2[NRB];
 #pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
+                    for (int rb = 0; rb < NRB; ++rb)
                         m2[rb] = fmaxf(fmaxf(keys[4 * rb], keys[4 * rb + 1]), fmaxf(keys[4 * rb + 2], keys[4 * rb + 3]));
-                    const float m = fmaxf(m2[0], m2[1]);
+                    const float m = NRB == 2 ? fmaxf(m2[0], m2[NRB - 1]) : m2[0];
                     const float tq = thr_q[qt][qb];
                     if (MODE == 0) {
                         run_max[qt][qb] = fmaxf(run_max[qt][qb], m);
@@ -305,7 +341,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
                         // short.  No atomic (the wave appends to its own ring segment), register groups without a
                         // candidate are skipped with one ballot, slots come from ballot + mbcnt.
 #pragma unroll
-                        for (int rb = 0; rb < 2; ++rb) {
+                        for (int rb = 0; rb < NRB; ++rb) {
                             if (__builtin_amdgcn_ballot_w64(m2[rb] >= tq) == 0ull) continue;  // wave-uniform
 #pragma unroll
                             for (int jj = 0; jj < 4; ++jj) {
@@ -319,8 +355,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
                                     if (is_cand && slot < (uint32_t)SEG) {
                                         const uint32_t e = (uint32_t)wave * SEG + slot;
                                         ring_key[e] = key;
-                                        ring_pos[e] = row0 + (uint32_t)(16 * rb + 4 * kg + jj);
-                                        ring_q[e] = (unsigned short)((wave * QT + qt) * 32 + qb * 16 + c16);
+                                        ring_pos[e] = row0 + (uint32_t)(rbase + 16 * rb + 4 * kg + jj);
+                                        ring_q[e] = (unsigned short)((qwave * QT + qt) * 32 + qb * 16 + c16);
                                     }
                                     my_cnt += (uint32_t)__popcll(mk);
                                 }
@@ -359,8 +395,27 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
                 float mx = run_max[qt][qb];  // the four k-groups of lanes saw different rows of one query
                 mx = fmaxf(mx, __shfl_xor(mx, 16));
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
-                if (q_valid[qt][qb] && kg == 0 && blockIdx.x < n_groups)
-                    gmax[(size_t)q[qt][qb] * n_groups + blockIdx.x] = enc_f(mx);
+                run_max[qt][qb] = mx;
+            }
+        if (KSPLIT == 2) {  // the pair saw different rows of the same queries: khalf 1 hands its maxima to khalf 0
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+                    if (khalf == 1 && kg == 0) rm_lds[((qwave * QT + qt) * 2 + qb) * 16 + c16] = run_max[qt][qb];
+            __syncthreads();
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+                    if (khalf == 0) run_max[qt][qb] = fmaxf(run_max[qt][qb], rm_lds[((qwave * QT + qt) * 2 + qb) * 16 + c16]);
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                if (q_valid[qt][qb] && kg == 0 && khalf == 0 && blockIdx.x < n_groups)
+                    gmax[(size_t)q[qt][qb] * n_groups + blockIdx.x] = enc_f(run_max[qt][qb]);
             }
     }
 }
@@ -582,12 +637,13 @@ __global__ __launch_bounds__(256) void k_rows_bf16(const double* __restrict__ ma
 namespace {
 // Launch shape of k_mfma_scan: 8 waves x 1 query tile (two waves share a SIMD), or 4 waves x 2 query
 // tiles (one wave per SIMD with the whole register file, every A fragment feeds two MFMAs).
-// dim >= 768 keeps 192 registers of fragments per tile, so it runs 4 waves x 1 tile.
+// dim 768 would keep 192 registers of query fragments per wave (one wave per SIMD: shape 41, 3.07 ms per
+// 1024-query pass over 1.25 M rows); its default is shape 82: 8 waves, each pair splitting K (2.85 ms).
 int env_shape(uint32_t ldb)
 {
     const char* v = getenv("VL_MFMA_SHAPE");
     const int want = v && *v ? atoi(v) : 0;
-    if (ldb >= 768) return 41;
+    if (ldb >= 768) return want == 41 ? 41 : 82;  // 82 = 8 waves, K split over wave pairs (k_mfma_scan: KSPLIT)
     if (want == 81 || want == 42 || want == 41) return want;
     return 81;
 }
@@ -637,8 +693,8 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     const uint32_t ldb = mfma_ldb(dim);
     // launch shape: (waves per workgroup, 32-query tiles per wave); 256 queries per workgroup
     const int shape = env_shape(ldb);  // 81 = 8 waves x 1 tile, 42 = 4 waves x 2 tiles, 41 = 4 waves x 1 tile
-    const int nwaves = shape / 10, qt = shape % 10;
-    const uint32_t qpb = (uint32_t)nwaves * 32 * (uint32_t)qt;
+    const int nwaves = shape / 10, qt = shape == 82 ? 1 : shape % 10;
+    const uint32_t qpb = (uint32_t)(shape == 82 ? nwaves / 2 : nwaves) * 32 * (uint32_t)qt;
     const uint32_t nq_pad = (nq + qpb - 1) / qpb * qpb;
     if (nq_pad > w.nq_cap) return hipErrorInvalidValue;
     const uint32_t n_tiles = (uint32_t)((n_rows + MF_ROWS - 1) / MF_ROWS);
@@ -683,9 +739,9 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     }
 
     bool launched = false;
-#define VL_LAUNCH3(K, MET, NW, QTT)                                                                                     \
+#define VL_LAUNCH3(K, MET, NW, QTT, KSP)                                                                                   \
     {                                                                                                                   \
-        hipLaunchKernelGGL((k_mfma_scan<K, 0, MET, NW, QTT>), grid0, dim3(NW * 64), 0, s, slab, row_norm, row_sqnorm, q16, nq,       \
+        hipLaunchKernelGGL((k_mfma_scan<K, 0, MET, NW, QTT, KSP>), grid0, dim3(NW * 64), 0, s, slab, row_norm, row_sqnorm, q16, nq,       \
                            sample_tiles, (uint32_t)sample_rows, w.gmax, n_groups, (const float*)nullptr,               \
                            (Cand32*)nullptr, (uint32_t*)nullptr, 0u, 0u);                                               \
         hipLaunchKernelGGL(k_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.gmax, n_groups, nq,                     \
@@ -693,7 +749,7 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
         for (int st = 0; st < n_stages; ++st) {                                                                         \
             const uint32_t tb = stage_end[st], te = stage_end[st + 1];                                                  \
             const dim3 grid1((uint32_t)std::min<uint32_t>(te - tb, (uint32_t)pass1_blocks), nq_pad / qpb);              \
-            hipLaunchKernelGGL((k_mfma_scan<K, 1, MET, NW, QTT>), grid1, dim3(NW * 64), 0, s, slab, row_norm, row_sqnorm, q16, nq,   \
+            hipLaunchKernelGGL((k_mfma_scan<K, 1, MET, NW, QTT, KSP>), grid1, dim3(NW * 64), 0, s, slab, row_norm, row_sqnorm, q16, nq,   \
                                te, (uint32_t)n_rows, (int*)nullptr, 0u, w.thr, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, tb); \
             if (st + 1 < n_stages)                                                                                      \
                 hipLaunchKernelGGL(k_refine_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.cand, w.cnt,             \
@@ -703,15 +759,20 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     }
 #define VL_LAUNCH2(K, MET)                                        \
     {                                                             \
-        if (shape == 81) VL_LAUNCH3(K, MET, 8, 1)                 \
-        else if (shape == 42) VL_LAUNCH3(K, MET, 4, 2)            \
-        else VL_LAUNCH3(K, MET, 4, 1)                             \
+        if (shape == 81) VL_LAUNCH3(K, MET, 8, 1, 1)              \
+        else if (shape == 42) VL_LAUNCH3(K, MET, 4, 2, 1)         \
+        else VL_LAUNCH3(K, MET, 4, 1, 1)                          \
     }
 #define VL_LAUNCH(K)                                              \
     if (!launched && ldb == (uint32_t)(K * 16)) {                 \
         if (metric == COSINE) VL_LAUNCH2(K, COSINE)               \
         else if (metric == EUCLIDEAN) VL_LAUNCH2(K, EUCLIDEAN)    \
         else VL_LAUNCH2(K, DOT)                                   \
+    }
+    if (shape == 82 && ldb == 768) {  // dim 768 with K split over wave pairs
+        if (metric == COSINE) VL_LAUNCH3(48, COSINE, 8, 1, 2)
+        else if (metric == EUCLIDEAN) VL_LAUNCH3(48, EUCLIDEAN, 8, 1, 2)
+        else VL_LAUNCH3(48, DOT, 8, 1, 2)
     }
     VL_MFMA_KSTEPS(VL_LAUNCH)
 #undef VL_LAUNCH
