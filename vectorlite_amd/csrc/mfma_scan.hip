@@ -692,7 +692,7 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     if (!mfma_scan_supported(dim, metric) || nq > w.nq_cap) return hipErrorInvalidValue;
     const uint32_t ldb = mfma_ldb(dim);
     // launch shape: (waves per workgroup, 32-query tiles per wave); 256 queries per workgroup
-    const int shape = env_shape(ldb);  // 81 = 8 waves x 1 tile, 42 = 4 waves x 2 tiles, 41 = 4 waves x 1 tile
+    const int shape = env_shape(ldb);  // 81 = 8 waves x 1 tile, 42 = 4 waves x 2 tiles, 41 = 4 waves x 1 tile, 82 = 8 waves, K split over pairs
     const int nwaves = shape / 10, qt = shape == 82 ? 1 : shape % 10;
     const uint32_t qpb = (uint32_t)(shape == 82 ? nwaves / 2 : nwaves) * 32 * (uint32_t)qt;
     const uint32_t nq_pad = (nq + qpb - 1) / qpb * qpb;
