@@ -34,7 +34,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 
 constexpr int MF_ROWS = 32;  // rows per tile (MFMA M)
-static_assert(MF_ROWS == (int)MFMA_TILE_ROWS, "the slab is allocated in whole tiles of this size");
+static_assert(2 * MF_ROWS == (int)MFMA_TILE_ROWS, "the slab is allocated in whole tiles of the largest shape (SUB = 2)");
 
 // order-preserving float <-> int (for max over possibly negative keys)
 __device__ __forceinline__ int enc_f(float f)
@@ -44,7 +44,7 @@ __device__ __forceinline__ int enc_f(float f)
 }
 __device__ __forceinline__ float dec_f(int e) { return __int_as_float(e >= 0 ? e : e ^ 0x7FFFFFFF); }
 
-template <int KSTEPS, int MODE, int METRIC, int NWAVES, int QT, int KSPLIT = 1>
+template <int KSTEPS, int MODE, int METRIC, int NWAVES, int QT, int KSPLIT = 1, int SUB = 1>
 __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restrict__ slab16,
                                                    const float* __restrict__ row_nrm,
                                                    const float* __restrict__ row_sqn,
@@ -58,7 +58,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
     // +32 B: a 16x16x32 A fragment is read as row (lane & 15) + 16 rb, 16 bytes at k-group (lane >> 4); with two
     // 16-byte slots of padding per row the 16 lanes of every ds_read_b128 group hit 16 distinct slots
     constexpr int LDS_ROW = ROW_BYTES + 32;
-    constexpr int CHUNKS = MF_ROWS * ROW_BYTES / 16;  // 16-byte pieces per tile
+    // SUB = 2: a tile is 64 rows = two 32-row MFMA blocks worked off one after the other between the same pair of
+    // barriers, which halves the workgroup barriers (and the per-tile staging code) per flop
+    static_assert(SUB == 1 || (SUB == 2 && KSPLIT == 1), "two sub-tiles only without the K split");
+    constexpr int TR = MF_ROWS * SUB;                 // rows per tile
+    constexpr int CHUNKS = TR * ROW_BYTES / 16;       // 16-byte pieces per tile
     constexpr int NT = NWAVES * 64;                   // threads per workgroup
     // KSPLIT = 2 (dim 768): waves w and w + QWAVES serve the SAME 32 QT queries, each over one half of K, so a wave
     // keeps half of the query fragments (96 instead of 192 VGPRs) and two waves fit on a SIMD; the partial sums
@@ -74,10 +78,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
     // the loop's vmcnt bookkeeping path-dependent and collapse the prefetch ring to depth 1.
     constexpr int RING = (MODE == 1) ? 1024 : 1;
     constexpr int XCH = (KSPLIT == 2) ? 2 * NWAVES * QT * 2 * 64 * 16 : 0;  // bytes of the partial-sum exchange
-    constexpr int NBUF = (2 * MF_ROWS * LDS_ROW + RING * 10 + XCH <= 150000) ? 2 : 1;  // gfx950: 160 KB of LDS per workgroup
-    __shared__ __attribute__((aligned(16))) unsigned char a_lds[NBUF][MF_ROWS * LDS_ROW];
-    __shared__ __attribute__((aligned(16))) float inv_lds[NBUF][MF_ROWS];  // |x|   (dot, Euclidean)
-    __shared__ __attribute__((aligned(16))) float sqn_lds[NBUF][MF_ROWS];  // |x|^2 (Euclidean)
+    constexpr int NBUF = (2 * TR * LDS_ROW + RING * 10 + XCH <= 150000) ? 2 : 1;  // gfx950: 160 KB of LDS per workgroup
+    __shared__ __attribute__((aligned(16))) unsigned char a_lds[NBUF][TR * LDS_ROW];
+    __shared__ __attribute__((aligned(16))) float inv_lds[NBUF][TR];  // |x|   (dot, Euclidean)
+    __shared__ __attribute__((aligned(16))) float sqn_lds[NBUF][TR];  // |x|^2 (Euclidean)
     __shared__ f32x4 xch[KSPLIT == 2 ? 2 : 1][KSPLIT == 2 ? NWAVES : 1][QT][2][KSPLIT == 2 ? 64 : 1];
     __shared__ float rm_lds[KSPLIT == 2 ? NWAVES * QT * 2 * 16 : 1];
     __shared__ float ring_key[RING];
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
         // Rows are dense (ROW_BYTES = CPR * 16), so a tile is ONE contiguous block: a workgroup-uniform base plus
         // 16 * (tid + i NT) per piece -- no per-piece row arithmetic, no clamp.  The slab is allocated in whole
         // tiles (MFMA_TILE_ROWS), so the last, partial tile reads rows past n_rows; the epilogue masks them.
-        const unsigned char* tbase = reinterpret_cast<const unsigned char*>(slab16) + (size_t)tile * (MF_ROWS * ROW_BYTES);
+        const unsigned char* tbase = reinterpret_cast<const unsigned char*>(slab16) + (size_t)tile * (TR * ROW_BYTES);
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             // plain (cacheable) loads on purpose: the workgroups of the other query chunks read the same
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
         }
         // The slab rows are unit-normalised (cosine needs no per-row scalar at all); dot restores
         // x.q = (x^.q) |x|, Euclidean uses key = 2 (x^.q) |x| - |x|^2.
-        const uint32_t arow_i = tile * MF_ROWS + (uint32_t)(tid & (MF_ROWS - 1));
+        const uint32_t arow_i = tile * TR + (uint32_t)(tid & (TR - 1));
         st_inv = (METRIC != COSINE) ? row_nrm[arow_i] : 1.0f;
         st_sqn = (METRIC == EUCLIDEAN) ? row_sqn[arow_i] : 0.0f;
     };
@@ -166,8 +170,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
             const int r = c / CPR, cc = c % CPR;
             *reinterpret_cast<u32x4*>(&a_lds[buf][r * LDS_ROW + cc * 16]) = st[i];
         }
-        if (METRIC != COSINE && tid < MF_ROWS) inv_lds[buf][tid] = st_inv;
-        if (METRIC == EUCLIDEAN && tid < MF_ROWS) sqn_lds[buf][tid] = st_sqn;
+        if (METRIC != COSINE && tid < TR) inv_lds[buf][tid] = st_inv;
+        if (METRIC == EUCLIDEAN && tid < TR) sqn_lds[buf][tid] = st_sqn;
     };
 
     if (t >= t_end) {  // nothing to do for this workgroup (uniform); MODE 0 still reports -inf maxima
@@ -233,6 +237,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
                 issue_loads(nt < t_end ? nt : t_last, stage[j], stage_inv[j], stage_sqn[j]);
             }
 
+#pragma unroll
+            for (int sub = 0; sub < SUB; ++sub) {
             f32x4 acc[QT][2][2];  // [row block][query block]: rows 16 rb + 4 kg + reg, query 16 qb + c16
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt)
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
             // A fragments are read from LDS one GROUP ahead of the MFMAs that consume them (left alone
             // the compiler reuses one register quad and every MFMA waits out an LDS round trip); each
             // fragment feeds 2 QT MFMAs.
-            const unsigned char* arow = &a_lds[buf][c16 * LDS_ROW + kg * 16 + khalf * (KSW * 64)];
+            const unsigned char* arow = &a_lds[buf][(sub * MF_ROWS + c16) * LDS_ROW + kg * 16 + khalf * (KSW * 64)];
             constexpr int GS = 2;            // K = 32 steps per group: 4 fragment reads, 8 QT MFMAs of 16 cycles
             constexpr int NG = KSW / GS;
             static_assert(KSW % GS == 0, "K steps come in whole groups");
@@ -296,11 +302,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
                     }
                 xpar ^= 1;
             }
-            const int rbase = (KSPLIT == 2) ? 16 * khalf : 0;  // first row of the block(s) this wave finishes
+            const int rbase = (KSPLIT == 2) ? 16 * khalf : sub * MF_ROWS;  // first row (in the tile) of the block(s) this wave finishes
             // C layout of a 16x16 block: column = lane & 15 (query), row = 4 (lane >> 4) + reg.
             // Epilogue on the common path = the key arithmetic, a max tree and ONE compare per query
             // against its threshold; the per-row work only runs for the rare tile that holds a candidate.
-            const uint32_t row0 = tile * MF_ROWS;
+            const uint32_t row0 = tile * TR;
             f32x4 aux[2], aux2[2];
             if (METRIC != COSINE) {
 #pragma unroll
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) aux2[rb] = *reinterpret_cast<const f32x4*>(&sqn_lds[buf][rbase + 16 * rb + 4 * kg]);
             }
-            const bool partial = row0 + MF_ROWS > n_rows || !tile_live;  // partial last tile / repeated tail tile (wave-uniform)
+            const bool partial = row0 + TR > n_rows || !tile_live;  // partial last tile / repeated tail tile (wave-uniform)
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
 #pragma unroll
@@ -365,6 +371,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
                     }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);  // keep the sub-tiles' epilogues apart (see below)
+            }  // sub
             if (NBUF == 1) __syncthreads();  // single buffer: everyone is done reading before the next write
             buf = (NBUF == 2) ? (buf ^ 1) : 0;
             // one scheduling region per tile: across the 16 unrolled tiles the scheduler otherwise
@@ -697,7 +705,10 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     const uint32_t qpb = (uint32_t)(shape == 82 ? nwaves / 2 : nwaves) * 32 * (uint32_t)qt;
     const uint32_t nq_pad = (nq + qpb - 1) / qpb * qpb;
     if (nq_pad > w.nq_cap) return hipErrorInvalidValue;
-    const uint32_t n_tiles = (uint32_t)((n_rows + MF_ROWS - 1) / MF_ROWS);
+    // the 8-wave shape works on 64-row tiles (two 32-row MFMA blocks per barrier), the others on 32-row tiles
+    // (up to d = 384; at 512 the eight 16-byte pieces per thread of a 64-row tile spill)
+    const uint32_t tile_rows = (shape == 81 && ldb <= 384) ? 2u * MF_ROWS : (uint32_t)MF_ROWS;
+    const uint32_t n_tiles = (uint32_t)((n_rows + tile_rows - 1) / tile_rows);
     __bf16* q16 = reinterpret_cast<__bf16*>(w.q_bf16);
     const __bf16* slab = reinterpret_cast<const __bf16*>(slab_bf16);
     {
@@ -714,11 +725,12 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     // ring segment.  A sample of at least 65536 rows (or the whole index) keeps that near 16; with only
     // 8192 sampled rows an index of 10^5 rows overflowed the rings and every query fell back.
     uint32_t sample_tiles = n_tiles / 16;
-    const uint32_t min_sample = n_tiles < 2048u ? n_tiles : 2048u;
+    const uint32_t min_tiles = 65536u / tile_rows;
+    const uint32_t min_sample = n_tiles < min_tiles ? n_tiles : min_tiles;
     if (sample_tiles < min_sample) sample_tiles = min_sample;
     const uint32_t n_groups = sample_tiles < (uint32_t)MFMA_GROUPS ? sample_tiles : (uint32_t)MFMA_GROUPS;
     const dim3 grid0(n_groups, nq_pad / qpb);
-    const uint64_t sample_rows = std::min<uint64_t>((uint64_t)sample_tiles * MF_ROWS, n_rows);
+    const uint64_t sample_rows = std::min<uint64_t>((uint64_t)sample_tiles * tile_rows, n_rows);
     // all query chunks of a launch are co-resident (one workgroup per CU) and walk the same tile
     // sequence, so a tile is fetched from HBM once and served to the other chunks by L2 / Infinity Cache
     const uint32_t n_chunks = nq_pad / qpb;
@@ -739,9 +751,9 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     }
 
     bool launched = false;
-#define VL_LAUNCH3(K, MET, NW, QTT, KSP)                                                                                   \
+#define VL_LAUNCH3(K, MET, NW, QTT, KSP, SUBP)                                                                                   \
     {                                                                                                                   \
-        hipLaunchKernelGGL((k_mfma_scan<K, 0, MET, NW, QTT, KSP>), grid0, dim3(NW * 64), 0, s, slab, row_norm, row_sqnorm, q16, nq,       \
+        hipLaunchKernelGGL((k_mfma_scan<K, 0, MET, NW, QTT, KSP, SUBP>), grid0, dim3(NW * 64), 0, s, slab, row_norm, row_sqnorm, q16, nq,       \
                            sample_tiles, (uint32_t)sample_rows, w.gmax, n_groups, (const float*)nullptr,               \
                            (Cand32*)nullptr, (uint32_t*)nullptr, 0u, 0u);                                               \
         hipLaunchKernelGGL(k_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.gmax, n_groups, nq,                     \
@@ -749,7 +761,7 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
         for (int st = 0; st < n_stages; ++st) {                                                                         \
             const uint32_t tb = stage_end[st], te = stage_end[st + 1];                                                  \
             const dim3 grid1((uint32_t)std::min<uint32_t>(te - tb, (uint32_t)pass1_blocks), nq_pad / qpb);              \
-            hipLaunchKernelGGL((k_mfma_scan<K, 1, MET, NW, QTT, KSP>), grid1, dim3(NW * 64), 0, s, slab, row_norm, row_sqnorm, q16, nq,   \
+            hipLaunchKernelGGL((k_mfma_scan<K, 1, MET, NW, QTT, KSP, SUBP>), grid1, dim3(NW * 64), 0, s, slab, row_norm, row_sqnorm, q16, nq,   \
                                te, (uint32_t)n_rows, (int*)nullptr, 0u, w.thr, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, tb); \
             if (st + 1 < n_stages)                                                                                      \
                 hipLaunchKernelGGL(k_refine_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.cand, w.cnt,             \
@@ -759,9 +771,9 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     }
 #define VL_LAUNCH2(K, MET)                                        \
     {                                                             \
-        if (shape == 81) VL_LAUNCH3(K, MET, 8, 1, 1)              \
-        else if (shape == 42) VL_LAUNCH3(K, MET, 4, 2, 1)         \
-        else VL_LAUNCH3(K, MET, 4, 1, 1)                          \
+        if (shape == 81) VL_LAUNCH3(K, MET, 8, 1, 1, (K <= 24 ? 2 : 1)) \
+        else if (shape == 42) VL_LAUNCH3(K, MET, 4, 2, 1, 1)      \
+        else VL_LAUNCH3(K, MET, 4, 1, 1, 1)                       \
     }
 #define VL_LAUNCH(K)                                              \
     if (!launched && ldb == (uint32_t)(K * 16)) {                 \
@@ -770,9 +782,9 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
         else VL_LAUNCH2(K, DOT)                                   \
     }
     if (shape == 82 && ldb == 768) {  // dim 768 with K split over wave pairs
-        if (metric == COSINE) VL_LAUNCH3(48, COSINE, 8, 1, 2)
-        else if (metric == EUCLIDEAN) VL_LAUNCH3(48, EUCLIDEAN, 8, 1, 2)
-        else VL_LAUNCH3(48, DOT, 8, 1, 2)
+        if (metric == COSINE) VL_LAUNCH3(48, COSINE, 8, 1, 2, 1)
+        else if (metric == EUCLIDEAN) VL_LAUNCH3(48, EUCLIDEAN, 8, 1, 2, 1)
+        else VL_LAUNCH3(48, DOT, 8, 1, 2, 1)
     }
     VL_MFMA_KSTEPS(VL_LAUNCH)
 #undef VL_LAUNCH

@@ -48,10 +48,10 @@ bool mfma_scan_supported(uint32_t dim, int metric);
 hipError_t launch_rows_bf16(hipStream_t s, const double* master, uint64_t n, uint32_t dim, void* out_bf16,
                             float* out_norm, float* out_sqnorm);
 
-// rows per k_mfma_scan tile.  The bf16 slab and the two per-row arrays must be ALLOCATED in whole tiles
+// rows per k_mfma_scan tile (its largest shape).  The bf16 slab and the two per-row arrays must be ALLOCATED in whole tiles
 // (ceil(n_rows / MFMA_TILE_ROWS) * MFMA_TILE_ROWS rows): the kernel fetches a tile as one contiguous block and masks
 // the rows past n_rows afterwards, whatever they hold.
-constexpr uint32_t MFMA_TILE_ROWS = 32;
+constexpr uint32_t MFMA_TILE_ROWS = 64;
 
 // nq queries (f64 [nq, dim]) against the bf16 slab: writes one sorted top-64 candidate list per query
 // (out_lists[nq][64], the layout k_merge_finalize takes with n_lists = 1).
