@@ -60,6 +60,22 @@ int main(void)
     if (vl_index_len(idx) != 2) return 1;
     vl_index_destroy(idx);
 
+    /* the ingest step in front of add: f32 model output, widened and L2-normalised on the device exactly as
+     * src/embeddings.rs:169-181 does on the host ({3,4} -> {0.6,0.8}; a zero row stays zero) */
+    vl_index *emb = NULL;
+    CHECK(vl_flat_create(2, 0, &emb));
+    const float model_out[3][2] = {{3.f, 4.f}, {0.f, 0.f}, {-5.f, 12.f}};
+    const uint64_t emb_ids[3] = {7, 8, 9};
+    CHECK(vl_index_add_embeddings_f32(emb, emb_ids, &model_out[0][0], 3, /*normalize=*/1, /*validate=*/1, /*on_device=*/0));
+    double stored[2];
+    CHECK(vl_index_get_vector(emb, 7, stored));
+    printf("embedding: stored row of id 7 = {%.17g, %.17g}\n", stored[0], stored[1]);
+    if (stored[0] != 3.0 / 5.0 || stored[1] != 4.0 / 5.0) return 1;
+    CHECK(vl_index_get_vector(emb, 8, stored));
+    if (stored[0] != 0.0 || stored[1] != 0.0) return 1;
+    if (vl_index_add_embeddings_f32(emb, emb_ids, &model_out[0][0], 1, 1, 1, 0) != VL_ERR_DUP_ID) return 1;
+    vl_index_destroy(emb);
+
     vl_index *hn = NULL;
     CHECK(vl_hnsw_create(3, VL_EUCLIDEAN, 0, &hn));
     const double hrows[4][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 1}};
