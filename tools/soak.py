@@ -14,7 +14,7 @@ t_end = time.time() + budget
 rounds = searches = 0
 low = free0
 while time.time() < t_end:
-    dim = int(rng.choice([64, 128, 384]))
+    dim = int(rng.choice([64, 128, 384, 768]))
     n = int(rng.choice([5000, 20000, 120000]))
     rows = rng.standard_normal((n, dim)); rows /= np.linalg.norm(rows, axis=1, keepdims=True)
     idx = V.FlatIndex(dim)
@@ -32,6 +32,7 @@ while time.time() < t_end:
     idx.set_coalescing(32, 100)
     th = [threading.Thread(target=lambda t=t: [idx.search_arrays(Q[(t * 5 + j) % 40], 10, 0) for j in range(5)]) for t in range(8)]
     [x.start() for x in th]; [x.join() for x in th]; searches += 40
+    e = V.FlatIndex(dim); e.add_embeddings(np.arange(3000, dtype=np.uint64), rows[:3000].astype(np.float32)); del e
     c = idx.clone()
     for j in range(20):
         c.delete(int(j * 3))
