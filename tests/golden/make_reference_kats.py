@@ -94,6 +94,12 @@ for d in (0.0, 100.0, 500.0, 1000.0, 1500.0, 2000.0):
 conversion_monotone = dict(src="src/index/hnsw.rs:933-953", distances=[0.0, 0.5, 1.0, 2.0, 5.0, 10.0],
                            metrics=["euclidean", "cosine", "manhattan"], start=1.0)
 
+# The ingest step (src/embeddings.rs:169-181).  The reference's own check needs its BERT model; what it asserts about
+# ANY output of generate_embedding is transcribed here as a property: the in-order f64 norm of the row is 1 +- 1e-10.
+embedding_kats = [
+    dict(src="src/embeddings.rs:374-383", property="l2_norm_is_one", tol=T),
+]
+
 hnsw_search_kats = [
     # What the reference's HNSW tests pin (Euclidean only): first id on well-separated points,
     # result-count bounds and descending order.  Any correct nearest-neighbour walk satisfies them.
@@ -113,6 +119,7 @@ out = dict(
     metric_kats=metric_kats, flat_kats=flat_kats, flat_pairs_differ=flat_pairs_differ,
     conversion_kats=conversion_kats, conversion_monotone=conversion_monotone,
     hnsw_search_kats=hnsw_search_kats,
+    embedding_kats=embedding_kats,
 )
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_kats.json")
 with open(path, "w") as f:

@@ -934,7 +934,7 @@ def _embedding_cases(rng):
 
 
 @pytest.mark.parametrize("normalize", [True, False])
-def test_embedding_ingest_is_bit_identical_to_host_postprocessing(V, O, normalize):
+def test_embedding_ingest_is_bit_identical_to_host_postprocessing(V, O, kats, normalize):
     """vl_index_add_embeddings_f32: widening + L2 normalisation on the device equals
     src/embeddings.rs:169-181 bit for bit, from host arrays and from device tensors."""
     import torch
@@ -948,6 +948,14 @@ def test_embedding_ingest_is_bit_identical_to_host_postprocessing(V, O, normaliz
             got_ids, got = idx.export()
             assert got_ids.tolist() == ids.tolist()
             assert np.array_equal(got.reshape(n, dim).view(np.uint64), want.view(np.uint64)), (n, dim, src)
+            if normalize:  # the reference's own assertion about generate_embedding's output (src/embeddings.rs:374-383)
+                tol = kats["embedding_kats"][0]["tol"]
+                for r in range(n):
+                    if e[r].any():
+                        acc = 0.0
+                        for x in got.reshape(n, dim)[r].tolist():
+                            acc += x * x
+                        assert abs(acc ** 0.5 - 1.0) < tol, (n, dim, r)
         # searching the ingested rows == searching an index built from the host-normalised rows
         ref = V.FlatIndex(dim)
         ref.add_rows(ids, want)

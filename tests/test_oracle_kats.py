@@ -178,7 +178,7 @@ def test_sum_identity_sign():
     assert math.copysign(1.0, O.calculate(O.DOT, [0.0], [1.0])) == 1.0
 
 
-def test_embedding_postprocessing_restatement():
+def test_embedding_postprocessing_restatement(kats):
     # src/embeddings.rs:169-181; the reference's own check is |norm - 1| < 1e-10 (src/embeddings.rs:374-383)
     assert O.embed_f32(np.array([3, 4], dtype=np.float32)).tolist() == [0.6, 0.8]
     assert O.embed_f32(np.array([3, 4], dtype=np.float32), normalize=False).tolist() == [3.0, 4.0]
@@ -198,4 +198,5 @@ def test_embedding_postprocessing_restatement():
             chk = -0.0
             for x in out[r].tolist():
                 chk += x * x
-            assert abs(math.sqrt(chk) - 1.0) < 1e-10
+            for kat in kats["embedding_kats"]:  # src/embeddings.rs:374-383
+                assert kat["property"] == "l2_norm_is_one" and abs(math.sqrt(chk) - 1.0) < kat["tol"]
