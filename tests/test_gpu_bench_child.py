@@ -1,0 +1,70 @@
+"""bench.py as the driver runs it: a fresh child process, the supervisor form, small sizes.
+Every field the measurement contract names must be on the ONE stdout line, for argument pairs that
+used to break the post-processing (few steps, no warmup)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(extra, timeout=600):
+    env = dict(os.environ)
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(v, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True,
+                       env=env, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout  # ONE JSON line
+    return json.loads(lines[0]), r.stderr
+
+
+@pytest.mark.parametrize("steps,warmup", [(3, 1), (1, 0)])
+def test_bench_child_process_prints_the_whole_contract_line(steps, warmup):
+    out, err = _run(["--gpus", "1", "--rows", "200000", "--steps", str(steps), "--warmup", str(warmup),
+                     "--cpu-sample-rows", "20000", "--cpu-queries", "4"])
+    assert "errors" not in out, out["errors"]
+    assert out["metric"].startswith("flat-cosine QPS") and out["unit"] == "queries/s"
+    assert out["n_gpus"] == 1 and out["steps"] == steps and out["warmup"] == warmup
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    assert out["dtype"] == "f32" and out["data"] == "synthetic" and out["scaling"] == "weak"
+    assert out["vs_baseline"] is None and out["higher_is_better"] is True
+    assert "workload" in out["config"] and "model" not in out["config"]
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert rf["launches_timed"] == steps  # HIP events saw exactly the timed launches
+    assert rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["algorithmic_bytes_per_launch"] == 200000 * 384 * 4
+    # kernel time fits inside the step time
+    assert rf["avg_launch_ms"] <= out["ms_per_step"] * 1.05
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+    par = out["parity"]
+    assert par["ids_bit_exact"] == "4/4" and par["max_abs_score_diff"] == 0.0 and par["recall_at_10"] == 1.0
+    assert out["config"]["fast_vs_exact_full_size"].startswith("4/4")
+    assert out["config"]["search_paths_seen"] == [1]  # PATH_FAST: the f32 scan is what was timed
+    assert out["config"]["prewarm_queries_untimed"] >= 10
+    assert "value_first_5_steps" in out
+
+
+def test_bench_two_ranks_without_an_external_launcher():
+    """`--gpus 2` alone starts two ranks (rehearsal: both on this card, gloo rendezvous)."""
+    env_before = os.environ.get("VL_BENCH_REHEARSE")
+    os.environ["VL_BENCH_REHEARSE"] = "1"
+    try:
+        out, err = _run(["--gpus", "2", "--rows", "100000", "--steps", "4", "--warmup", "1"])
+    finally:
+        if env_before is None:
+            os.environ.pop("VL_BENCH_REHEARSE", None)
+        else:
+            os.environ["VL_BENCH_REHEARSE"] = env_before
+    assert out["n_gpus"] == 2 and out["steps"] == 4
+    assert "replicas" in out["config"]["parallelism"]
+    assert out["value"] > 0 and out["roofline"]["launches_timed"] == 4
+    assert "cpu_baseline" not in out  # rank 0 at N = 1 only
