@@ -127,7 +127,9 @@ int vl_index_add_embeddings_f32(vl_index *h, const uint64_t *ids, const float *e
 int vl_index_delete(vl_index *h, uint64_t id);
 
 /* search(query, k, metric) (src/index/flat.rs:98-119): writes min(k, len) results, best first,
- * ties in insertion order.  out_ids/out_scores must hold min(k, len) entries.
+ * ties in insertion order.  out_ids/out_scores must hold min(k, len) entries; a caller that sized its
+ * buffers from an earlier vl_index_len() passes k = min(k, capacity) -- results for a smaller k are a prefix
+ * of those for a larger k, so the call can never write past the buffer even if the index grew since.
  * Empty index: any q_len is accepted and *out_n = 0.  Otherwise q_len != dim ->
  * VL_ERR_DIM_MISMATCH (vl_last_dim_mismatch gives expected/actual). */
 int vl_index_search(const vl_index *h, const double *query, uint64_t q_len, uint64_t k, int metric,
@@ -201,6 +203,52 @@ int vl_index_search_positions(const vl_index *h, const double *query, uint64_t q
 int vl_index_search_batch_positions(const vl_index *h, const double *queries, uint64_t nq, uint64_t q_len,
                                     uint64_t k, int metric, uint64_t *out_pos, uint64_t *out_ids,
                                     double *out_scores, uint64_t *out_n);
+
+/* ---- row-sharded batched search over RCCL (north_star's config 3; no reference counterpart) ----------
+ *
+ * One process per GPU.  Rank r holds the contiguous row range [offset_r, offset_r + len_r) of the corpus as an
+ * ordinary flat handle (vl_flat_create + vl_index_add_bulk ...).  A batch is answered by every rank on its own
+ * shard with the single-GPU pipeline (exact f64 scores), ONE ncclAllGather over xGMI exchanges the per-shard
+ * top-k records, and a device kernel merges them by (score desc, GLOBAL position asc) -- the reference's stable
+ * sort (src/index/flat.rs:116) applied to the whole corpus, so the answer is bit-identical to one index holding
+ * every row.  All ranks must make the same calls with the same queries / k / metric; errors of any one shard
+ * travel inside the exchange, so every rank returns the same status and nobody is left waiting.
+ *
+ * vl_comm_unique_id: rank 0 makes the ncclUniqueId and hands the 128 bytes to the other ranks by whatever
+ * channel the host has (the Rust server would use its own RPC; the Python harness broadcasts it with
+ * torch.distributed).  vl_comm_create is collective (ncclCommInitRank). */
+#define VL_COMM_ID_BYTES 128
+typedef struct vl_comm vl_comm;
+int vl_comm_unique_id(uint8_t *out_id);
+int vl_comm_create(const uint8_t *id, int world, int rank, int device, vl_comm **out);
+void vl_comm_destroy(vl_comm *comm);
+int vl_comm_world(const vl_comm *comm);
+int vl_comm_rank(const vl_comm *comm);
+
+/* Collective: the ranks exchange (len, dimension) of their shards; each learns the global position of its
+ * first row (*out_offset, rank order) and the total row count.  Call after building the shards and again
+ * after any add/delete on any of them; a shard that changed since is reported as VL_ERR_INVALID_ARG by the
+ * next search on every rank. */
+int vl_shard_sync(const vl_index *shard, vl_comm *comm, uint64_t *out_offset, uint64_t *out_total);
+
+/* Collective: nq searches over the WHOLE sharded corpus; outputs as vl_index_search_batch ([nq, k], row
+ * stride k; out_n[q] = min(k, total rows)), identical on every rank.  out_gpos (optional) receives global
+ * storage positions.  Semantics per query are FlatIndex::search's (src/index/flat.rs:98-119) on the union:
+ * empty corpus accepts any q_len; otherwise q_len != dim -> VL_ERR_DIM_MISMATCH; NaN -> VL_ERR_NAN_SCORE. */
+int vl_shard_search_batch(const vl_index *shard, vl_comm *comm, const double *queries, uint64_t nq, uint64_t q_len,
+                          uint64_t k, int metric, uint64_t *out_gpos, uint64_t *out_ids, double *out_scores,
+                          uint64_t *out_n);
+
+/* The two halves of vl_shard_search_batch for a host that moves the records with its own transport (MPI, gloo,
+ * the server's RPC): vl_shard_search_local fills this shard's exchange record (vl_shard_packed_words(nq, ks)
+ * u64 words; ks = min(k, longest shard); the local status travels in word 0 and the call itself returns VL_OK
+ * unless an argument is null), the host gathers the `world` records in rank order, and vl_shard_merge runs the
+ * same device merge kernel on them. */
+uint64_t vl_shard_packed_words(uint64_t nq, uint64_t ks);
+int vl_shard_search_local(const vl_index *shard, uint64_t row_offset, int corpus_has_rows, const double *queries,
+                          uint64_t nq, uint64_t q_len, uint64_t ks, int metric, uint64_t *out_packed);
+int vl_shard_merge(int device, const uint64_t *gathered, uint32_t world, uint64_t nq, uint64_t ks, uint64_t k,
+                   uint64_t *out_gpos, uint64_t *out_ids, double *out_scores, uint64_t *out_n);
 
 /* ---- HNSW distance callbacks (src/index/hnsw.rs:113-174) ------------------ */
 

@@ -113,10 +113,14 @@ impl Handle {
     }
 
     fn search(&self, query: &[f64], k: usize, metric: SimilarityMetric) -> VectorLiteResult<Vec<SearchResult>> {
+        // The library writes min(k, len at search time) entries and takes no capacity argument, so the k handed
+        // over is clamped to the buffer: results for a smaller k are a prefix of those for a larger one, and the
+        // call can never write past `cap` even if another handle user grew the index after len() was read
+        // (in Rust `&mut self` on add already excludes that; a C or Python caller has no such lock).
         let cap = k.min(self.len()).max(1);
         let (mut ids, mut scores, mut n) = (vec![0u64; cap], vec![0f64; cap], 0u64);
         let rc = unsafe {
-            vl_index_search(self.raw, query.as_ptr(), query.len() as u64, k as u64, metric_code(metric), ids.as_mut_ptr(), scores.as_mut_ptr(), &mut n)
+            vl_index_search(self.raw, query.as_ptr(), query.len() as u64, k.min(cap) as u64, metric_code(metric), ids.as_mut_ptr(), scores.as_mut_ptr(), &mut n)
         };
         match rc {
             VL_OK => Ok((0..n as usize)

@@ -261,11 +261,14 @@ class FlatIndex:
     # ---- array-level entry points -----------------------------------------------------------
     def search_arrays(self, query, k: int, metric: int = 0) -> Tuple[np.ndarray, np.ndarray]:
         q = _f64(query).ravel()
+        # The ABI writes min(k, len at search time) entries and has no capacity argument: k is clamped to the
+        # buffer, so a concurrent add() from another thread (ctypes drops the GIL) between len() and the search
+        # cannot make the library write past it -- results for a smaller k are a prefix of those for a larger k.
         m = max(min(int(k), self.len()), 1)
         ids = np.empty(m, dtype=np.uint64)
         scores = np.empty(m, dtype=np.float64)
         n = C.c_uint64(0)
-        _raise(self._L.vl_index_search(self._h, _pf64(q), q.size, int(k), int(metric), _pu64(ids), _pf64(scores),
+        _raise(self._L.vl_index_search(self._h, _pf64(q), q.size, min(int(k), m), int(metric), _pu64(ids), _pf64(scores),
                                        C.byref(n)))
         return ids[: n.value].copy(), scores[: n.value].copy()
 
@@ -277,7 +280,7 @@ class FlatIndex:
         ids = np.empty(m, dtype=np.uint64)
         scores = np.empty(m, dtype=np.float64)
         n = C.c_uint64(0)
-        _raise(self._L.vl_index_search_positions(self._h, _pf64(q), q.size, int(k), int(metric), _pu64(pos),
+        _raise(self._L.vl_index_search_positions(self._h, _pf64(q), q.size, min(int(k), m), int(metric), _pu64(pos),
                                                  _pu64(ids), _pf64(scores), C.byref(n)))
         return pos[: n.value].copy(), ids[: n.value].copy(), scores[: n.value].copy()
 

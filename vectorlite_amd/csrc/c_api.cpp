@@ -7,6 +7,7 @@
 
 #include "flat_index.hpp"
 #include "hnsw_index.hpp"
+#include "shard.hpp"
 #include "vlc_loader.hpp"
 
 // enum VectorIndexWrapper { Flat(FlatIndex), HNSW(Box<HNSWIndex>) } (src/lib.rs:271-276): exactly one
@@ -15,6 +16,11 @@
 struct vl_index {
     vl::GpuFlatIndex* flat;
     vl::HnswIndex* hnsw;
+};
+
+// one rank's end of the RCCL communicator of a row-sharded index (shard.hpp)
+struct vl_comm {
+    vl::ShardComm* c;
 };
 
 namespace {
@@ -245,6 +251,100 @@ int vl_index_search_batch_positions(const vl_index* h, const double* queries, ui
         VL_FLAT_ONLY(h);
         if (!out_n && nq) return VL_ERR_INVALID_ARG;
         return h->flat->search_batch(queries, nq, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
+    });
+}
+
+// ---- row-sharded batched search over RCCL (shard.hpp) ----------------------------------------------------
+int vl_comm_unique_id(uint8_t* out_id)
+{
+    return guarded([&]() -> int { return vl::ShardComm::unique_id(out_id); });
+}
+
+int vl_comm_create(const uint8_t* id, int world, int rank, int device, vl_comm** out)
+{
+    return guarded([&]() -> int {
+        if (!out) return VL_ERR_INVALID_ARG;
+        *out = nullptr;
+        vl::ShardComm* c = nullptr;
+        const int rc = vl::ShardComm::create(id, world, rank, device, &c);
+        if (rc != VL_OK) return rc;
+        vl_comm* h = new (std::nothrow) vl_comm{c};
+        if (!h) {
+            delete c;
+            return VL_ERR_OOM;
+        }
+        *out = h;
+        return VL_OK;
+    });
+}
+
+void vl_comm_destroy(vl_comm* comm)
+{
+    if (!comm) return;
+    try {
+        delete comm->c;
+    } catch (...) {
+    }
+    delete comm;
+}
+
+int vl_comm_world(const vl_comm* comm) { return comm && comm->c ? comm->c->world() : 0; }
+int vl_comm_rank(const vl_comm* comm) { return comm && comm->c ? comm->c->rank() : -1; }
+
+int vl_shard_sync(const vl_index* shard, vl_comm* comm, uint64_t* out_offset, uint64_t* out_total)
+{
+    return guarded([&]() -> int {
+        VL_FLAT_ONLY(shard);
+        if (!comm || !comm->c) return VL_ERR_INVALID_ARG;
+        return comm->c->sync(shard->flat, out_offset, out_total);
+    });
+}
+
+int vl_shard_search_batch(const vl_index* shard, vl_comm* comm, const double* queries, uint64_t nq, uint64_t q_len,
+                          uint64_t k, int metric, uint64_t* out_gpos, uint64_t* out_ids, double* out_scores,
+                          uint64_t* out_n)
+{
+    return guarded([&]() -> int {
+        VL_FLAT_ONLY(shard);
+        if (!comm || !comm->c) return VL_ERR_INVALID_ARG;
+        return comm->c->search_batch(shard->flat, queries, nq, q_len, k, metric, out_gpos, out_ids, out_scores, out_n);
+    });
+}
+
+uint64_t vl_shard_packed_words(uint64_t nq, uint64_t ks) { return vl::shard_packed_words(nq, ks); }
+
+int vl_shard_search_local(const vl_index* shard, uint64_t row_offset, int corpus_has_rows, const double* queries,
+                          uint64_t nq, uint64_t q_len, uint64_t ks, int metric, uint64_t* out_packed)
+{
+    return guarded([&]() -> int {
+        VL_FLAT_ONLY(shard);
+        if (!out_packed || metric < 0 || metric > 3) return VL_ERR_INVALID_ARG;
+        vl::shard_search_local(shard->flat, row_offset, UINT64_MAX, corpus_has_rows != 0, queries, nq, q_len, ks, metric,
+                               reinterpret_cast<unsigned long long*>(out_packed));
+        return VL_OK;  // the search's own status is word 0 of the record
+    });
+}
+
+int vl_shard_merge(int device, const uint64_t* gathered, uint32_t world, uint64_t nq, uint64_t ks, uint64_t k,
+                   uint64_t* out_gpos, uint64_t* out_ids, double* out_scores, uint64_t* out_n)
+{
+    return guarded([&]() -> int {
+        if (nq == 0) return VL_OK;
+        if (!out_n) return VL_ERR_INVALID_ARG;
+        for (uint64_t i = 0; i < nq; ++i) out_n[i] = 0;
+        if (k == 0 || ks == 0) return VL_OK;
+        if (!gathered || !out_scores || world == 0 || world > (uint32_t)vl::SHARD_MAX_WORLD || nq > 0x7FFFFFFFull ||
+            ks > 0x7FFFFFFFull || vl::shard_packed_words(nq, ks) * world > (1ull << 29))
+            return VL_ERR_INVALID_ARG;
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) {
+            (void)hipGetLastError();
+            vl::set_last_error("no usable HIP device (vectorlite_amd has no CPU fallback)");
+            return VL_ERR_DEVICE;
+        }
+        vl::ShardMerger m(device);  // buffers per call: this is the bring-your-own-transport path
+        return m.merge_host(reinterpret_cast<const unsigned long long*>(gathered), world, nq, ks, k, out_gpos, out_ids,
+                            out_scores, out_n);
     });
 }
 

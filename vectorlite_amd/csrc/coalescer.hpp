@@ -62,14 +62,33 @@ public:
                     ++it;
                 }
             }
+            // Whatever exec does -- return, or throw -- the batch is released: followers already taken off the
+            // queue are marked done and the leader slot is freed, so nobody waits for a pass that will never come.
+            // exec's contract is to answer every request (an rc per request) and not to throw; if it throws anyway
+            // the requests it left unanswered keep their initial rc, which callers initialise to an error.
+            struct Release {
+                Coalescer* c;
+                std::unique_lock<std::mutex>& lk;
+                std::vector<Req*>& batch;
+                ~Release()
+                {
+                    if (!lk.owns_lock()) lk.lock();
+                    for (Req* o : batch) o->done = true;
+                    c->leader_ = false;
+                    c->cv_.notify_all();
+                }
+            };
             lk.unlock();
             batches_.fetch_add(1);
             queries_.fetch_add(batch.size());
-            exec(batch);
-            lk.lock();
-            for (Req* o : batch) o->done = true;
-            leader_ = false;
-            cv_.notify_all();
+            {
+                Release rel{this, lk, batch};
+                try {
+                    exec(batch);
+                } catch (...) {
+                    // swallowed: no exception may cross the C ABI from a follower's pass either
+                }
+            }
         }
     }
 

@@ -233,13 +233,23 @@ int GpuFlatIndex::ensure_capacity(uint64_t rows)
         return rc;
     }
     const uint64_t n = ids_.size();
+    hipError_t ce = hipSuccess;
     if (n) {
-        VL_HIP(hipMemcpyAsync(m, d_master_, n * dim_ * sizeof(double), hipMemcpyDeviceToDevice, mut_stream_));
-        VL_HIP(hipMemcpyAsync(s, d_slab_, n * ld_ * sizeof(float), hipMemcpyDeviceToDevice, mut_stream_));
-        VL_HIP(hipMemcpyAsync(inv, d_inv_norm_, n * sizeof(float), hipMemcpyDeviceToDevice, mut_stream_));
-        VL_HIP(hipMemcpyAsync(fl, d_flags_, n, hipMemcpyDeviceToDevice, mut_stream_));
+        ce = hipMemcpyAsync(m, d_master_, n * dim_ * sizeof(double), hipMemcpyDeviceToDevice, mut_stream_);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(s, d_slab_, n * ld_ * sizeof(float), hipMemcpyDeviceToDevice, mut_stream_);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(inv, d_inv_norm_, n * sizeof(float), hipMemcpyDeviceToDevice, mut_stream_);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(fl, d_flags_, n, hipMemcpyDeviceToDevice, mut_stream_);
     }
-    VL_HIP(hipStreamSynchronize(mut_stream_));
+    const hipError_t se = hipStreamSynchronize(mut_stream_);
+    if (ce == hipSuccess) ce = se;
+    if (ce != hipSuccess) {  // the old buffers stay the index; the new ones are not leaked
+        (void)hipFree(m);
+        (void)hipFree(s);
+        (void)hipFree(inv);
+        (void)hipFree(fl);
+        set_last_error(std::string("growing the row store failed: ") + hipGetErrorString(ce));
+        return ERR_DEVICE;
+    }
     if (d_master_) (void)hipFree(d_master_);
     if (d_slab_) (void)hipFree(d_slab_);
     if (d_inv_norm_) (void)hipFree(d_inv_norm_);
@@ -526,7 +536,14 @@ void GpuFlatIndex::run_coalesced(std::vector<CoalesceReq*>& batch) const
         one(batch[0]);
         return;
     }
-    const uint64_t nq = batch.size(), k = batch[0]->k;
+    // scratch and row stride use min(k, len), never the caller's raw k: k = u64::MAX would throw length_error,
+    // k = 2^63 with two queries would wrap nq * k to 0 (mutators are exclusive, so len cannot move under a search)
+    uint64_t n_rows;
+    {
+        std::shared_lock<std::shared_mutex> lk(mu_);
+        n_rows = ids_.size();
+    }
+    const uint64_t nq = batch.size(), k = std::min<uint64_t>(batch[0]->k, n_rows);
     int rc = OK;
     try {
         std::vector<double> q(nq * dim_);
@@ -550,7 +567,7 @@ void GpuFlatIndex::run_coalesced(std::vector<CoalesceReq*>& batch) const
             }
             return;
         }
-    } catch (const std::bad_alloc&) {
+    } catch (...) {  // bad_alloc, length_error: answer the callers one by one instead
         rc = ERR_OOM;
     }
     for (CoalesceReq* o : batch) one(o);  // per-caller errors (src/index/flat.rs:116 panics only the offending search)
@@ -981,9 +998,24 @@ int GpuFlatIndex::ensure_bf16_slab() const
     if (!d_slab16_) {
         // whole MFMA tiles: k_mfma_scan reads the last, partial tile past the live rows (and masks them)
         const size_t cap16 = (cap_ + MFMA_TILE_ROWS - 1) / MFMA_TILE_ROWS * MFMA_TILE_ROWS;
-        VL_HIP(hipMalloc(&d_slab16_, cap16 * (size_t)ldb * 2));
-        VL_HIP(hipMalloc(reinterpret_cast<void**>(&d_sqnorm_), cap16 * sizeof(float)));
-        VL_HIP(hipMalloc(reinterpret_cast<void**>(&d_norm16_), cap16 * sizeof(float)));
+        // all three or none: a half-made set would let the next call skip allocation and launch with null pointers
+        void* s16 = nullptr;
+        float* sq = nullptr;
+        float* nr = nullptr;
+        hipError_t e = hipMalloc(&s16, cap16 * (size_t)ldb * 2);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sq), cap16 * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&nr), cap16 * sizeof(float));
+        if (e != hipSuccess) {
+            if (s16) (void)hipFree(s16);
+            if (sq) (void)hipFree(sq);
+            if (nr) (void)hipFree(nr);
+            (void)hipGetLastError();
+            set_last_error(std::string("bf16 slab allocation failed: ") + hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? ERR_OOM : ERR_DEVICE;
+        }
+        d_slab16_ = s16;
+        d_sqnorm_ = sq;
+        d_norm16_ = nr;
         slab16_rows_ = 0;
     }
     if (slab16_rows_ < n) {

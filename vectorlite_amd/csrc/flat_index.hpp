@@ -95,9 +95,9 @@ public:
         uint64_t* out_ids;
         double* out_scores;
         uint64_t* out_n;
-        int rc = 0;
+        int rc = 6;  // ERR_DEVICE until the pass answers it (a pass that dies must not read as success)
         int path = 0;
-        std::string err;
+        std::string err = "coalesced pass ended without answering this request";
         bool done = false;
     };
 

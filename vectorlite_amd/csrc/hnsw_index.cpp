@@ -241,8 +241,6 @@ int HnswIndex::add_bulk(const uint64_t* ids, const double* values, uint64_t n, b
         set_last_error("row store and graph out of step");
         return ERR_DEVICE;
     }
-    VL_TRY(store_->add_bulk(ids, values, n_take, /*validate=*/false, values_on_device));
-
     // node levels and upper-layer slots
     std::vector<uint8_t> lv(n_take);
     std::vector<uint32_t> off(n_take);
@@ -253,7 +251,12 @@ int HnswIndex::add_bulk(const uint64_t* ids, const double* values, uint64_t n, b
         off[i] = (uint32_t)upper;
         upper += (uint64_t)l;
     }
+    // Everything that can run out of memory comes BEFORE the row store is touched: if growing the graph arrays or
+    // the visited stamps fails, nothing has been appended and the index still answers and accepts adds.  What is
+    // left after the rows are in (copies and launches on an allocated graph) fails only with the device itself.
     VL_TRY(ensure_graph(first + n_take, upper));
+    VL_TRY(store_->reserve(first + n_take));
+    VL_TRY(store_->add_bulk(ids, values, n_take, /*validate=*/false, values_on_device));
     VL_HIP(hipMemcpyAsync(d_level_ + first, lv.data(), n_take, hipMemcpyHostToDevice, stream_));
     VL_HIP(hipMemcpyAsync(d_upper_off_ + first, off.data(), n_take * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
     VL_HIP(hipStreamSynchronize(stream_));  // lv/off are stack-owned
@@ -314,10 +317,11 @@ int HnswIndex::remove(uint64_t id)
         set_last_error("Vector ID " + std::to_string(id) + " does not exist");
         return ERR_NOT_FOUND;
     }
-    live_[it->second] = 0;  // tombstone: the node stays in the graph and is still walked (:407)
+    // tombstone: the node stays in the graph and is still walked (:407); host state follows the device's
     VL_HIP(hipSetDevice(device_));
     VL_HIP(hipMemsetAsync(d_live_ + it->second, 0, 1, stream_));
     VL_HIP(hipStreamSynchronize(stream_));
+    live_[it->second] = 0;
     id_to_node_.erase(it);
     --live_count_;
     return OK;
@@ -503,7 +507,7 @@ int HnswIndex::search(const double* query, uint64_t q_len, uint64_t k, int metri
         [this](std::vector<CoalesceReq*>& batch) {
             const uint64_t nq = batch.size(), kk = batch[0]->k;
             int rc = OK;
-            if (nq > 1) {
+            if (nq > 1) try {
                 std::vector<double> q(nq * dim_);
                 for (uint64_t i = 0; i < nq; ++i) std::memcpy(q.data() + i * dim_, batch[i]->query, dim_ * sizeof(double));
                 std::vector<uint64_t> ids(nq * kk), cnt(nq);
@@ -521,6 +525,7 @@ int HnswIndex::search(const double* query, uint64_t q_len, uint64_t k, int metri
                     }
                     return;
                 }
+            } catch (...) {  // host allocation failed: the callers are answered one by one below
             }
             for (CoalesceReq* o : batch) {  // alone, or the batch failed as a whole: per-caller status
                 o->rc = search_batch(o->query, 1, dim_, o->k, metric_, o->ef, o->out_ids, o->out_scores, o->out_n);
@@ -569,7 +574,11 @@ int HnswIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_len, 
 
     VL_HIP(hipSetDevice(device_));
     std::lock_guard<std::mutex> sg(search_mu_);
-    VL_TRY(ensure_search_scratch(nq, k));
+    // Device and pinned scratch, and the kernel's output stride, are sized by the beam (kd <= HNSW_MAX_EF entries
+    // per query), never by the caller's k: a huge k on a small index must return min(k, len) results, not OOM, and
+    // nq * (2k + 1) must not be able to wrap.  k is used only for the caller's own [nq, k] row stride.
+    const uint64_t kd = max_candidates;
+    VL_TRY(ensure_search_scratch(nq, kd));
     // straight from the caller's buffer (the runtime stages pageable memory itself; an extra copy into a pinned
     // staging area cost 12 % of a 2000-query batch); the stream is synchronised before this call returns
     VL_HIP(hipMemcpyAsync(d_q_, queries, nq * dim_ * sizeof(double), hipMemcpyHostToDevice, stream_));
@@ -579,18 +588,18 @@ int HnswIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_len, 
     // tombstones can make fewer than k results come back; unlike it, the slots they free are refilled from the rest
     // of the beam when ef > k.
     unsigned long long* d_ids = d_out_;
-    double* d_scores = reinterpret_cast<double*>(d_out_ + nq * k);
-    unsigned long long* d_n = d_out_ + 2 * nq * k;
+    double* d_scores = reinterpret_cast<double*>(d_out_ + nq * kd);
+    unsigned long long* d_n = d_out_ + 2 * nq * kd;
     VL_HIP(launch_hnsw_search(stream_, metric_, g, d_q_, (uint32_t)nq, (uint32_t)ef_walk, entry_, max_level_,
-                              (uint32_t)max_candidates, (uint32_t)k, d_ids, d_scores, d_n, d_stat_evals_));
-    VL_HIP(hipMemcpyAsync(h_out_, d_out_, nq * (2 * k + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+                              (uint32_t)max_candidates, (uint32_t)kd, d_ids, d_scores, d_n, d_stat_evals_));
+    VL_HIP(hipMemcpyAsync(h_out_, d_out_, nq * (2 * kd + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
     VL_HIP(hipStreamSynchronize(stream_));
     stat_queries_.fetch_add(nq, std::memory_order_relaxed);
-    const unsigned long long* h_n = h_out_ + 2 * nq * k;
+    const unsigned long long* h_n = h_out_ + 2 * nq * kd;
     for (uint64_t qi = 0; qi < nq; ++qi) {
-        const uint64_t m = std::min<uint64_t>(h_n[qi], k);
-        std::memcpy(out_ids + qi * k, h_out_ + qi * k, m * sizeof(uint64_t));
-        std::memcpy(out_scores + qi * k, h_out_ + nq * k + qi * k, m * sizeof(double));
+        const uint64_t m = std::min<uint64_t>(h_n[qi], kd);
+        std::memcpy(out_ids + qi * k, h_out_ + qi * kd, m * sizeof(uint64_t));
+        std::memcpy(out_scores + qi * k, h_out_ + nq * kd + qi * kd, m * sizeof(double));
         out_n[qi] = m;
     }
     return OK;

@@ -36,8 +36,8 @@ public:
         uint64_t* out_ids;
         double* out_scores;
         uint64_t* out_n;
-        int rc = 0;
-        std::string err;
+        int rc = 6;  // ERR_DEVICE until the walk answers it
+        std::string err = "coalesced walk ended without answering this request";
         bool done = false;
     };
     // concurrent single-query search() calls share walk launches (coalescer.hpp); 0 / 1 = off (default)

@@ -23,6 +23,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <cmath>
+#include <cstdlib>
 #include <charconv>
 #include <cstring>
 #include <memory>
@@ -334,8 +336,17 @@ int64_t convert_values(const char* tok, uint64_t len, uint64_t dim, double* out,
         double v = 0.0;
         auto r = std::from_chars(s, e, v);
         if (r.ec == std::errc::result_out_of_range) {
-            *err = "number out of range in `values`";
-            return -1;
+            // from_chars reports overflow AND underflow this way.  serde_json rejects only the former
+            // ("number out of range"); 1e-400 is 0.0 and 1e-310 a subnormal there.  strtod tells them apart
+            // (correctly rounded in glibc): +-HUGE_VAL means overflow, anything else is the value.
+            const std::string tok(s, r.ptr);
+            const double t = std::strtod(tok.c_str(), nullptr);
+            if (t == HUGE_VAL || t == -HUGE_VAL) {
+                *err = "number out of range in `values`";
+                return -1;
+            }
+            v = t;
+            r.ec = std::errc();
         }
         if (r.ec != std::errc() || r.ptr == s || r.ptr[-1] == '.' || (r.ptr < e && *r.ptr == '.')) {
             *err = "invalid number in `values`";

@@ -1,23 +1,38 @@
-"""Row-sharded flat index across the GPUs of one node (one process per GPU, torch.distributed).
+"""Row-sharded flat index across the GPUs of one node: host harness over the C ABI's vl_comm_* / vl_shard_*
+entry points (include/vectorlite_amd.h; design in csrc/shard.hpp).
 
-No reference counterpart: the reference is single-process.  The north star shards the
-*batched* flat search by rows: rank r holds the contiguous row range [offset_r, offset_r + n_r) of the
-corpus, every rank scans its own shard with the same HIP path as the single-GPU index, and ONE
-all-gather (RCCL over xGMI with backend "nccl"; gloo in the CPU tests) exchanges the per-shard exact
-top-k.  Because each shard returns the reference's exact f64 scores, merging is just the reference's
-ordering on the union: score descending, ties by GLOBAL storage position (shard offset + local
-position) ascending -- identical to a single index holding all rows (src/index/flat.rs:116).
+No reference counterpart: the reference is single-process.  north_star shards the
+*batched* flat search by rows: rank r holds the contiguous row range [offset_r, offset_r + n_r) of the corpus,
+every rank scans its own shard with the same HIP path as the single-GPU index, ONE all-gather exchanges the
+per-shard exact top-k, and a device kernel merges by (score desc, GLOBAL position asc) -- identical to one index
+holding all rows (src/index/flat.rs:116), bit for bit, because every shard returns exact f64 scores.
 
-Exchange size: nq * (k + 1) * 24 bytes per rank (config 3: 1024 queries, k = 10 -> 270 KB per rank):
+Everything numeric is in libvectorlite_amd.so.  This module only (1) hands rank 0's ncclUniqueId to the other
+ranks (torch.distributed's store / broadcast -- the job a Rust server's own RPC would do) and (2) offers two
+transports for the one exchange:
+
+  transport="rccl"   vl_shard_search_batch: local search -> ncclAllGather inside the library -> device merge.
+                     The production form (one process per GPU, xGMI).
+  transport="torch"  vl_shard_search_local -> torch.distributed.all_gather_into_tensor (gloo in the tests, where
+                     several ranks share one card and RCCL refuses that) -> vl_shard_merge (the same device
+                     merge kernel).
+
+Exchange size: 8 * (4 + nq + 3 * nq * ks) bytes per rank (config 3: 1024 queries, k = 10 -> 254 KB per rank):
 latency-bound, so it is a single collective, not a ring of small ones.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+import ctypes as C
+from typing import Tuple
 
 import numpy as np
 
-__all__ = ["ShardedFlatIndex", "merge_shard_results", "shard_ranges"]
+from . import _lib
+
+__all__ = ["ShardedFlatIndex", "Comm", "shard_ranges", "pack_words", "unpack_record"]
+
+VL_COMM_ID_BYTES = 128
+SHARD_HDR_WORDS = 4
 
 
 def shard_ranges(n_rows: int, world: int):
@@ -29,107 +44,183 @@ def shard_ranges(n_rows: int, world: int):
     return starts
 
 
-def merge_shard_results(scores: np.ndarray, gpos: np.ndarray, ids: np.ndarray, counts: np.ndarray, k: int):
-    """Merge per-shard top-k lists of ONE query.
+def pack_words(nq: int, ks: int) -> int:
+    """vl_shard_packed_words: u64 words of one rank's exchange record."""
+    return SHARD_HDR_WORDS + nq + 3 * nq * ks
 
-    scores/gpos/ids: [world, k]; counts: [world].  Returns (ids, scores, gpos) of the global top-k in
-    the reference's order: score descending, global position ascending on ties."""
-    sel_s, sel_p, sel_i = [], [], []
-    for r in range(scores.shape[0]):
-        c = int(counts[r])
-        sel_s.append(scores[r, :c])
-        sel_p.append(gpos[r, :c])
-        sel_i.append(ids[r, :c])
-    s = np.concatenate(sel_s) if sel_s else np.zeros(0)
-    p = np.concatenate(sel_p) if sel_p else np.zeros(0, dtype=np.int64)
-    i = np.concatenate(sel_i) if sel_i else np.zeros(0, dtype=np.uint64)
-    order = np.lexsort((p, -s))  # primary: -score ascending (= score descending); secondary: position
-    order = order[:k]
-    return i[order], s[order], p[order]
+
+def unpack_record(rec: np.ndarray, nq: int, ks: int):
+    """One exchange record -> (status, shard_len, dim, counts [nq], scores [nq, ks] f64, gpos [nq, ks], ids [nq, ks])."""
+    rec = np.ascontiguousarray(rec, dtype=np.uint64)
+    cnt = rec[SHARD_HDR_WORDS: SHARD_HDR_WORDS + nq]
+    body = rec[SHARD_HDR_WORDS + nq:].reshape(3, nq, ks)
+    return int(rec[0]), int(rec[1]), int(rec[2]), cnt, body[0].view(np.float64), body[1], body[2]
+
+
+def _pu64(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def _pf64(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Comm:
+    """vl_comm: one rank's end of the RCCL communicator (ncclCommInitRank from a caller-supplied ncclUniqueId)."""
+
+    def __init__(self, unique_id: bytes, world: int, rank: int, device: int):
+        from . import _raise
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        if len(unique_id) != VL_COMM_ID_BYTES:
+            raise ValueError("unique_id must be the 128 bytes vl_comm_unique_id returned on rank 0")
+        buf = (C.c_uint8 * VL_COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _raise(self._L.vl_comm_create(buf, int(world), int(rank), int(device), C.byref(self._h)))
+
+    @staticmethod
+    def unique_id() -> bytes:
+        from . import _raise
+        buf = (C.c_uint8 * VL_COMM_ID_BYTES)()
+        _raise(_lib.load().vl_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def from_torch_distributed(cls, device: int, group=None) -> "Comm":
+        """Every rank of an initialised torch.distributed group calls this: rank 0's id travels by broadcast."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(box[0], world, rank, device)
+
+    @property
+    def world(self) -> int:
+        return int(self._L.vl_comm_world(self._h))
+
+    @property
+    def rank(self) -> int:
+        return int(self._L.vl_comm_rank(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.vl_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ShardedFlatIndex:
     """One rank's view of a row-sharded flat index.
 
-    `local` is this rank's shard: a `vectorlite_amd.FlatIndex` on this rank's GPU (anything exposing
-    `search_positions(query, k, metric)` and `len()` works, which is how the CPU tests drive the
-    collective path).  `offset` is the global position of the shard's first row.
-    """
+    `local`: this rank's shard, a `vectorlite_amd.FlatIndex` on this rank's GPU.
+    transport "rccl": `comm` is a `Comm`; offsets come from vl_shard_sync.
+    transport "torch": torch.distributed (any backend) moves the records; the merge still runs on the device.
+    Call `sync()` after building the shards and after any add/delete."""
 
-    def __init__(self, local, offset: int, group=None, device=None):
+    def __init__(self, local, comm: Comm = None, transport: str = None, group=None, gather_device=None):
+        self._L = _lib.load()
         self.local = local
-        self.offset = int(offset)
+        self.comm = comm
+        self.transport = transport or ("rccl" if comm is not None else "torch")
         self.group = group
-        self.device = device
-        try:
+        self.gather_device = gather_device  # torch transport: where the gathered tensor lives (None = CPU, gloo)
+        self.offset = 0
+        self.total = 0
+        self.max_len = 0
+        if self.transport == "rccl":
+            if comm is None:
+                raise ValueError('transport "rccl" needs a Comm')
+            self.world, self.rank = comm.world, comm.rank
+        elif self.transport == "torch":
             import torch.distributed as dist
             self._dist = dist if (dist.is_available() and dist.is_initialized()) else None
-        except Exception:  # pragma: no cover
-            self._dist = None
-        self.world = self._dist.get_world_size(group) if self._dist else 1
-        self.rank = self._dist.get_rank(group) if self._dist else 0
+            self.world = self._dist.get_world_size(group) if self._dist else 1
+            self.rank = self._dist.get_rank(group) if self._dist else 0
+        else:
+            raise ValueError("transport must be 'rccl' or 'torch'")
+        self.sync()
 
-    # ---- collective ---------------------------------------------------------------------------
-    def _all_gather(self, packed: np.ndarray) -> np.ndarray:
-        """packed: int64 [m]; returns [world, m]."""
+    # ---- the table every rank agrees on ---------------------------------------------------------------
+    def _torch_all_gather(self, words: np.ndarray) -> np.ndarray:
+        """u64 [m] -> [world, m] through torch.distributed (one collective)."""
         if self.world == 1:
-            return packed[None, :]
+            return words[None, :].copy()
         import torch
-        t = torch.from_numpy(packed)
-        if self.device is not None:
-            t = t.to(self.device)
+        t = torch.from_numpy(words.view(np.int64))
+        if self.gather_device is not None:
+            t = t.to(self.gather_device)
         out = torch.empty(self.world * t.numel(), dtype=torch.int64, device=t.device)
-        self._dist.all_gather_into_tensor(out, t, group=self.group)  # one collective (RCCL on GPU ranks)
-        return out.cpu().numpy().reshape(self.world, -1)
+        self._dist.all_gather_into_tensor(out, t, group=self.group)
+        return out.cpu().numpy().view(np.uint64).reshape(self.world, -1)
 
-    def search_batch(self, queries, k: int, metric: int = 0) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    def sync(self) -> Tuple[int, int]:
+        """Collective.  Returns (this shard's global offset, total rows)."""
+        from . import _raise
+        if self.transport == "rccl":
+            off, tot = C.c_uint64(0), C.c_uint64(0)
+            _raise(self._L.vl_shard_sync(self.local._h, self.comm._h, C.byref(off), C.byref(tot)))
+            self.offset, self.total = int(off.value), int(tot.value)
+            self.max_len = None  # kept inside the library
+        else:
+            mine = np.array([len(self.local), self.local.dimension()], dtype=np.uint64)
+            allv = self._torch_all_gather(mine)
+            if len(set(allv[:, 1].tolist())) != 1:
+                raise ValueError(f"shards disagree on the dimension: {allv[:, 1].tolist()}")
+            lens = allv[:, 0].astype(np.int64)
+            self.offset, self.total, self.max_len = int(lens[: self.rank].sum()), int(lens.sum()), int(lens.max())
+        return self.offset, self.total
+
+    def global_len(self) -> int:
+        return self.total
+
+    # ---- search ---------------------------------------------------------------------------------------
+    def search_batch(self, queries, k: int, metric: int = 0, with_positions: bool = False):
         """nq independent searches over the whole (sharded) corpus.
-        Returns (ids [nq, k], scores [nq, k], n [nq]); identical on every rank."""
+        Returns (ids [nq, k], scores [nq, k], n [nq]) -- identical on every rank (+ gpos [nq, k] on request)."""
+        from . import _raise
         Q = np.ascontiguousarray(np.asarray(queries, dtype=np.float64))
         if Q.ndim == 1:
             Q = Q[None, :]
-        nq = Q.shape[0]
-        kk = max(int(k), 1)
-        # per query: kk rows of (score bits, global pos, id bits) + 1 row whose first word is the count
-        packed = np.zeros((nq, kk + 1, 3), dtype=np.int64)
-        if len(self.local) != 0 and k != 0:
-            if hasattr(self.local, "search_batch_positions"):  # GPU shard: queries share slab passes
-                bpos, bids, bsc, bn = self.local.search_batch_positions(Q, k, metric)
-                packed[:, : int(k), 0] = np.ascontiguousarray(bsc, dtype=np.float64).view(np.int64)
-                packed[:, : int(k), 1] = bpos.astype(np.int64) + self.offset
-                packed[:, : int(k), 2] = np.ascontiguousarray(bids, dtype=np.uint64).view(np.int64)
-                packed[:, kk, 0] = bn.astype(np.int64)
-            else:
-                for qi in range(nq):
-                    pos, ids, scores = self.local.search_positions(Q[qi], k, metric)
-                    c = len(pos)
-                    packed[qi, :c, 0] = np.asarray(scores, dtype=np.float64).view(np.int64)
-                    packed[qi, :c, 1] = np.asarray(pos, dtype=np.int64) + self.offset
-                    packed[qi, :c, 2] = np.asarray(ids, dtype=np.uint64).view(np.int64)
-                    packed[qi, kk, 0] = c
-        gathered = self._all_gather(packed.reshape(-1)).reshape(self.world, nq, kk + 1, 3)
-        # merge for all queries at once: [nq, world * kk] candidates, entries beyond a shard's count pushed
-        # behind everything, then the reference's order -- score descending, global position ascending
-        counts = gathered[:, :, kk, 0]                                             # [world, nq]
-        valid = np.arange(kk)[None, None, :] < counts[:, :, None]                  # [world, nq, kk]
-        sc = np.ascontiguousarray(gathered[:, :, :kk, 0]).view(np.float64)
-        sc = np.where(valid, sc, -np.inf).transpose(1, 0, 2).reshape(nq, -1)
-        gp = np.where(valid, gathered[:, :, :kk, 1], np.iinfo(np.int64).max).transpose(1, 0, 2).reshape(nq, -1)
-        gi = gathered[:, :, :kk, 2].transpose(1, 0, 2).reshape(nq, -1)
-        order = np.lexsort((gp, -sc), axis=-1)[:, :kk]
-        total = np.minimum(counts.sum(axis=0), int(k)).astype(np.uint64)           # [nq]
-        out_scores = np.take_along_axis(sc, order, axis=1)
-        out_ids = np.ascontiguousarray(np.take_along_axis(gi, order, axis=1)).view(np.uint64)
-        live = np.arange(kk)[None, :] < total[:, None]
-        out_scores = np.where(live, out_scores, 0.0)
-        out_ids = np.where(live, out_ids, np.uint64(0))
-        return out_ids[:, : int(k)], out_scores[:, : int(k)], total
+        nq, qlen = Q.shape
+        k = int(k)
+        kk = max(min(k, max(self.total, 1)), 1)  # output row stride: min(k, total rows) results at most
+        ids = np.zeros((nq, kk), dtype=np.uint64)
+        gpos = np.zeros((nq, kk), dtype=np.uint64)
+        scores = np.zeros((nq, kk), dtype=np.float64)
+        n = np.zeros(max(nq, 1), dtype=np.uint64)
+        k_call = min(k, kk)  # results for a smaller k are a prefix: the buffers can never be overrun
+        if self.transport == "rccl":
+            _raise(self._L.vl_shard_search_batch(self.local._h, self.comm._h, _pf64(Q), nq, qlen, k_call, int(metric),
+                                                 _pu64(gpos), _pu64(ids), _pf64(scores), _pu64(n)))
+        elif k_call > 0 and self.total > 0 and nq > 0:
+            ks = min(k_call, self.max_len)
+            rec = self._local_record(Q, ks, int(metric))
+            gathered = np.ascontiguousarray(self._torch_all_gather(rec))
+            self._merge(gathered, nq, ks, k_call, gpos, ids, scores, n)
+        out = (ids[:, :k_call], scores[:, :k_call], n[:nq])
+        return out + (gpos[:, :k_call],) if with_positions else out
+
+    # the two halves around the "torch" transport's exchange; both are one C-ABI call
+    def _local_record(self, Q: np.ndarray, ks: int, metric: int) -> np.ndarray:
+        """vl_shard_search_local: this shard's exchange record for the batch (status in word 0)."""
+        from . import _raise
+        nq, qlen = Q.shape
+        rec = np.zeros(pack_words(nq, ks), dtype=np.uint64)
+        _raise(self._L.vl_shard_search_local(self.local._h, self.offset, 1 if self.total else 0, _pf64(Q), nq, qlen, ks,
+                                             metric, _pu64(rec)))
+        return rec
+
+    def _merge(self, gathered: np.ndarray, nq: int, ks: int, k: int, gpos, ids, scores, n) -> None:
+        """vl_shard_merge: the device merge kernel over the `world` gathered records."""
+        from . import _raise
+        _raise(self._L.vl_shard_merge(int(self.local.device), _pu64(gathered), self.world, nq, ks, k, _pu64(gpos),
+                                      _pu64(ids), _pf64(scores), _pu64(n)))
 
     def search(self, query, k: int, metric: int = 0):
         ids, scores, n = self.search_batch(np.asarray(query, dtype=np.float64)[None, :], k, metric)
         m = int(n[0])
         return ids[0, :m].copy(), scores[0, :m].copy()
-
-    def global_len(self) -> int:
-        n = np.array([len(self.local)], dtype=np.int64)
-        return int(self._all_gather(n).sum())
