@@ -24,6 +24,10 @@ pub struct vl_index {
 pub struct vl_vlc_doc {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct vl_comm {
+    _private: [u8; 0],
+}
 
 extern "C" {
     fn vl_flat_create(dim: u64, device: c_int, out: *mut *mut vl_index) -> c_int;
@@ -47,7 +51,15 @@ extern "C" {
     fn vl_vlc_build_index(doc: *const vl_vlc_doc, device: c_int, out: *mut *mut vl_index) -> c_int;
     fn vl_last_error() -> *const c_char;
     fn vl_last_dim_mismatch(expected: *mut u64, actual: *mut u64);
+    // row-sharded batched search: one process per GPU, one RCCL all-gather per batch
+    fn vl_comm_unique_id(out_id: *mut u8) -> c_int;
+    fn vl_comm_create(id: *const u8, world: c_int, rank: c_int, device: c_int, out: *mut *mut vl_comm) -> c_int;
+    fn vl_comm_destroy(comm: *mut vl_comm);
+    fn vl_shard_sync(shard: *const vl_index, comm: *mut vl_comm, out_offset: *mut u64, out_total: *mut u64) -> c_int;
+    fn vl_shard_search_batch(shard: *const vl_index, comm: *mut vl_comm, queries: *const f64, nq: u64, q_len: u64, k: u64, metric: c_int, out_gpos: *mut u64, out_ids: *mut u64, out_scores: *mut f64, out_n: *mut u64) -> c_int;
 }
+
+pub const VL_COMM_ID_BYTES: usize = 128;
 
 const VL_OK: c_int = 0;
 const VL_ERR_DIM_MISMATCH: c_int = 1;
@@ -275,6 +287,79 @@ impl<'de> Deserialize<'de> for GpuFlatIndex {
     fn deserialize<D: Deserializer<'de>>(d: D) -> Result<Self, D::Error> {
         let p = FlatPayload::deserialize(d)?;
         Ok(GpuFlatIndex::new(p.dim, p.data))
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-sharded flat index: one process per GPU, this process holds the rows [offset, offset + len) of the corpus.
+// Every rank calls the same methods with the same arguments (the library's all-gather is collective).
+// ------------------------------------------------------------------------------------------------
+pub struct ShardedGpuFlatIndex {
+    shard: GpuFlatIndex,
+    comm: *mut vl_comm,
+    pub offset: u64,
+    pub total: u64,
+}
+unsafe impl Send for ShardedGpuFlatIndex {}
+unsafe impl Sync for ShardedGpuFlatIndex {}
+
+impl ShardedGpuFlatIndex {
+    /// Rank 0 creates the id and ships the 128 bytes to the other ranks over the server's own channel.
+    pub fn unique_id() -> [u8; VL_COMM_ID_BYTES] {
+        let mut id = [0u8; VL_COMM_ID_BYTES];
+        let rc = unsafe { vl_comm_unique_id(id.as_mut_ptr()) };
+        assert_eq!(rc, VL_OK, "vl_comm_unique_id: {}", last_error());
+        id
+    }
+
+    /// Collective (ncclCommInitRank, then the length exchange).
+    pub fn new(shard: GpuFlatIndex, id: &[u8; VL_COMM_ID_BYTES], world: usize, rank: usize, device: i32) -> Result<Self, String> {
+        let mut comm = std::ptr::null_mut();
+        if unsafe { vl_comm_create(id.as_ptr(), world as c_int, rank as c_int, device as c_int, &mut comm) } != VL_OK {
+            return Err(last_error());
+        }
+        let mut s = ShardedGpuFlatIndex { shard, comm, offset: 0, total: 0 };
+        s.sync()?;
+        Ok(s)
+    }
+
+    /// Collective; call again after add/delete on any shard.
+    pub fn sync(&mut self) -> Result<(), String> {
+        match unsafe { vl_shard_sync(self.shard.0.raw, self.comm, &mut self.offset, &mut self.total) } {
+            VL_OK => Ok(()),
+            _ => Err(last_error()),
+        }
+    }
+
+    pub fn shard_mut(&mut self) -> &mut GpuFlatIndex {
+        &mut self.shard
+    }
+
+    /// Collective: nq searches over the whole corpus; identical on every rank; row q is exactly what
+    /// `FlatIndex::search(queries[q])` returns on one index holding every shard's rows in rank order.
+    pub fn search_batch(&self, queries: &[f64], nq: usize, k: usize, metric: SimilarityMetric) -> VectorLiteResult<Vec<Vec<(u64, f64)>>> {
+        let dim = self.shard.0.dim;
+        assert_eq!(queries.len(), nq * dim);
+        let stride = k.min(self.total as usize).max(1); // at most min(k, total) results; k is clamped to the buffers
+        let (mut ids, mut scores, mut n) = (vec![0u64; nq * stride], vec![0f64; nq * stride], vec![0u64; nq]);
+        let rc = unsafe {
+            vl_shard_search_batch(self.shard.0.raw, self.comm, queries.as_ptr(), nq as u64, dim as u64, k.min(stride) as u64, metric_code(metric), std::ptr::null_mut(), ids.as_mut_ptr(), scores.as_mut_ptr(), n.as_mut_ptr())
+        };
+        match rc {
+            VL_OK => Ok((0..nq).map(|q| (0..n[q] as usize).map(|i| (ids[q * stride + i], scores[q * stride + i])).collect()).collect()),
+            VL_ERR_DIM_MISMATCH => {
+                let (mut e, mut a) = (0u64, 0u64);
+                unsafe { vl_last_dim_mismatch(&mut e, &mut a) };
+                Err(VectorLiteError::DimensionMismatch { expected: e as usize, actual: a as usize })
+            }
+            _ => Err(VectorLiteError::InternalError(last_error())),
+        }
+    }
+}
+
+impl Drop for ShardedGpuFlatIndex {
+    fn drop(&mut self) {
+        unsafe { vl_comm_destroy(self.comm) };
     }
 }
 

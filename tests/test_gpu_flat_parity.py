@@ -436,7 +436,8 @@ def test_sharded_index_single_rank_equals_flat(V, O):
     gpu = V.FlatIndex(dim)
     gpu.add_rows(ids, rows, validate=False)
     ref = O.FlatOracle(dim, ids, rows)
-    sh = ShardedFlatIndex(gpu, offset=0)
+    sh = ShardedFlatIndex(gpu, transport="torch")  # no process group: a world of one, device merge all the same
+    assert (sh.offset, sh.total, sh.world) == (0, n, 1)
     Q = unit_rows(rng, 11, dim)
     for m in range(4):
         bi, bs, bn = sh.search_batch(Q, 10, m)
