@@ -306,6 +306,12 @@ def step_rates(stamps, t_start: float) -> dict:
 
 
 def run_rank(args) -> int:
+    # ONE JSON line on stdout means nothing else may land there: RCCL prints its version banner to STDOUT when
+    # the first communicator is made (seen with torch's nccl backend and with vl_comm_create).  Everything this
+    # process and its libraries write to fd 1 goes to stderr; the line itself is written to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -323,8 +329,13 @@ def run_rank(args) -> int:
     dev_index = local_rank % torch.cuda.device_count() if rehearse else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # under a launcher (WORLD_SIZE set) the process group is made even for one rank, so that the RCCL branch
+    # (init, barrier, device all-reduce) is the same code at N = 1 as at N = 8
+    use_dist = "WORLD_SIZE" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
         if rehearse:
             dist.init_process_group("gloo")
         else:
@@ -334,7 +345,7 @@ def run_rank(args) -> int:
     if not os.path.exists(vbuild.SO):  # normally prebuilt by __graft_entry__.build(); never build concurrently
         if rank == 0:
             vbuild.build()
-        if world > 1:
+        if use_dist:
             dist.barrier()
     import vectorlite_amd as V
 
@@ -380,7 +391,7 @@ def run_rank(args) -> int:
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     # fixed pre-warm, outside the timed region and independent of --warmup
@@ -408,14 +419,13 @@ def run_rank(args) -> int:
     n_launch, scan_ms, scan_bytes = idx.profile_read()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t.item())
 
     if rank != 0:
-        if world > 1:
-            dist.barrier()  # rank 0 has published the line
-            dist.destroy_process_group()
+        dist.barrier()  # rank 0 has published the line
+        dist.destroy_process_group()
         return 0
 
     qps = world * args.steps / elapsed_max
@@ -495,7 +505,7 @@ def run_rank(args) -> int:
     publish()  # the contract line exists from here on
     log(f"[bench] timed region: {qps:.1f} q/s, {out['ms_per_step']} ms/step, k_scan {achieved:.0f} GB/s "
         f"({out['roofline']['frac']:.3f} of peak)")
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     extras = world == 1 and not args.no_checks  # N>1: every rank leaves together, nothing runs on rank 0 alone
@@ -614,8 +624,9 @@ def run_rank(args) -> int:
 
     publish()
     if not args.result_file:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if use_dist:
         dist.destroy_process_group()
     return 0
 
