@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libvectorlite_amd.so")
+# VL_LIB_PATH: diagnostic builds of the same library (tools/, kernel anatomy runs); never a different implementation
+SO_PATH = os.environ.get("VL_LIB_PATH") or os.path.join(_HERE, "libvectorlite_amd.so")
 
 # every symbol include/vectorlite_amd.h declares
 SYMBOLS = [

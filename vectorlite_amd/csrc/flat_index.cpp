@@ -188,7 +188,7 @@ GpuFlatIndex::~GpuFlatIndex()
     (void)hipSetDevice(device_);
     ws_all_.clear();
     if (mut_stream_) (void)hipStreamSynchronize(mut_stream_);
-    void* dev[] = {d_master_, d_slab_, d_inv_norm_, d_flags_, d_stats_, d_bounce_, d_slab16_, d_sqnorm_, d_norm16_};
+    void* dev[] = {d_master_, d_slab_, d_inv_norm_, d_flags_, d_stats_, d_bounce_, d_slab16_, d_sqnorm_, d_norm16_, d_slab16f_};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     if (mut_stream_) (void)hipStreamDestroy(mut_stream_);
@@ -259,14 +259,17 @@ int GpuFlatIndex::ensure_capacity(uint64_t rows)
     d_inv_norm_ = inv;
     d_flags_ = fl;
     cap_ = new_cap;
-    if (d_slab16_) {  // rebuilt on demand by the next large batch
-        (void)hipFree(d_slab16_);
+    if (d_norm16_) {  // rebuilt on demand by the next large batch
+        if (d_slab16_) (void)hipFree(d_slab16_);
+        if (d_slab16f_) (void)hipFree(d_slab16f_);
         (void)hipFree(d_sqnorm_);
         (void)hipFree(d_norm16_);
         d_slab16_ = nullptr;
+        d_slab16f_ = nullptr;
         d_sqnorm_ = nullptr;
         d_norm16_ = nullptr;
         slab16_rows_ = 0;
+        slab16f_rows_ = 0;
     }
     return OK;
 }
@@ -397,6 +400,7 @@ int GpuFlatIndex::remove_position(uint64_t pos)
     }
     if (row_flags_[pos] & ROW_OUT_OF_DOMAIN) --n_out_of_domain_;
     if (slab16_rows_ > pos) slab16_rows_ = pos;  // rows behind the hole are re-converted on demand
+    if (slab16f_rows_ > pos) slab16f_rows_ = pos;
     ids_.erase(ids_.begin() + pos);
     row_flags_.erase(row_flags_.begin() + pos);
     return OK;
@@ -767,7 +771,7 @@ int GpuFlatIndex::search_locked(Workspace* ws, const double* query, uint64_t k_e
     // rarely certifies (dense neighbourhoods).
     if (fast_ok && single_filter_.load() == 1 && scan_bf16_supported((uint32_t)dim_, metric) &&
         !(bf16_tries_.load() >= 64 && bf16_fails_.load() * 3 > bf16_tries_.load())) {
-        VL_TRY(ensure_bf16_slab());
+        VL_TRY(ensure_bf16_slab(false));
         const bool prof = profile_.load();
         int grid = 0;
         if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
@@ -990,40 +994,53 @@ int GpuFlatIndex::run_exact(Workspace* ws, int metric, uint64_t n, uint64_t k_ef
 // ---------------------------------------------------------------------------------------------
 // large batches: bf16 MFMA candidate filter (mfma_scan.hip) + the same exact finalize
 // ---------------------------------------------------------------------------------------------
-int GpuFlatIndex::ensure_bf16_slab() const
+int GpuFlatIndex::ensure_bf16_slab(bool frag_major) const
 {
     std::lock_guard<std::mutex> g(bf16_mu_);
     const uint64_t n = ids_.size();
     const uint32_t ldb = mfma_ldb((uint32_t)dim_);
-    if (!d_slab16_) {
-        // whole MFMA tiles: k_mfma_scan reads the last, partial tile past the live rows (and masks them)
-        const size_t cap16 = (cap_ + MFMA_TILE_ROWS - 1) / MFMA_TILE_ROWS * MFMA_TILE_ROWS;
-        // all three or none: a half-made set would let the next call skip allocation and launch with null pointers
-        void* s16 = nullptr;
+    // whole MFMA tiles: the batch kernels read the last, partial tile past the live rows (and mask them)
+    const size_t cap16 = (cap_ + MFMA_TILE_ROWS - 1) / MFMA_TILE_ROWS * MFMA_TILE_ROWS;
+    auto fail = [&](hipError_t e) {
+        (void)hipGetLastError();
+        set_last_error(std::string("bf16 slab allocation failed: ") + hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? (int)ERR_OOM : (int)ERR_DEVICE;
+    };
+    if (!d_norm16_) {  // both per-row arrays or neither: a half-made set would be launched with null pointers next time
         float* sq = nullptr;
         float* nr = nullptr;
-        hipError_t e = hipMalloc(&s16, cap16 * (size_t)ldb * 2);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sq), cap16 * sizeof(float));
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&sq), cap16 * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&nr), cap16 * sizeof(float));
         if (e != hipSuccess) {
-            if (s16) (void)hipFree(s16);
             if (sq) (void)hipFree(sq);
             if (nr) (void)hipFree(nr);
-            (void)hipGetLastError();
-            set_last_error(std::string("bf16 slab allocation failed: ") + hipGetErrorString(e));
-            return e == hipErrorOutOfMemory ? ERR_OOM : ERR_DEVICE;
+            return fail(e);
         }
-        d_slab16_ = s16;
         d_sqnorm_ = sq;
         d_norm16_ = nr;
-        slab16_rows_ = 0;
     }
-    if (slab16_rows_ < n) {
-        char* dst = reinterpret_cast<char*>(d_slab16_) + slab16_rows_ * (size_t)ldb * 2;
-        VL_HIP(launch_rows_bf16(mut_stream_, d_master_ + slab16_rows_ * dim_, n - slab16_rows_, (uint32_t)dim_, dst,
-                                d_norm16_ + slab16_rows_, d_sqnorm_ + slab16_rows_));
+    void*& slab = frag_major ? d_slab16f_ : d_slab16_;
+    uint64_t& rows_done = frag_major ? slab16f_rows_ : slab16_rows_;
+    if (!slab) {
+        void* s16 = nullptr;
+        const hipError_t e = hipMalloc(&s16, cap16 * (size_t)ldb * 2);
+        if (e != hipSuccess) return fail(e);
+        slab = s16;
+        rows_done = 0;
+    }
+    if (rows_done < n) {
+        if (frag_major) {
+            // the fragment layout interleaves 16 neighbouring rows: conversion restarts at the group boundary
+            const uint64_t first = rows_done & ~15ull;
+            VL_HIP(launch_rows_bf16_frag(mut_stream_, d_master_ + first * dim_, first, n - first, (uint32_t)dim_, slab, d_norm16_,
+                                         d_sqnorm_));
+        } else {
+            char* dst = reinterpret_cast<char*>(slab) + rows_done * (size_t)ldb * 2;
+            VL_HIP(launch_rows_bf16(mut_stream_, d_master_ + rows_done * dim_, n - rows_done, (uint32_t)dim_, dst,
+                                    d_norm16_ + rows_done, d_sqnorm_ + rows_done));
+        }
         VL_HIP(hipStreamSynchronize(mut_stream_));
-        slab16_rows_ = n;
+        rows_done = n;
     }
     return OK;
 }
@@ -1053,7 +1070,9 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, uint64
                                     uint64_t* out_n, std::vector<uint8_t>* done) const
 {
     const uint64_t n = ids_.size();
-    VL_TRY(ensure_bf16_slab());
+    const bool frag = mfma_rows_kernel((uint32_t)dim_);  // which kernel, hence which slab layout
+    VL_TRY(ensure_bf16_slab(frag));
+    const void* slab16 = frag ? d_slab16f_ : d_slab16_;
     VL_TRY(ensure_mfma_scratch(ws));
     hipStream_t st = ws->stream;
     // (2 + u) * u with u = 2^-8 + 2^-23 (f64 -> f32 -> bf16 double rounding), see DESIGN.md
@@ -1067,7 +1086,7 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, uint64
             in_domain[j] = stage_query(queries + (q0 + j) * dim_, ws->mf_h_q64 + (size_t)j * dim_, dim_, &norms[j]) ? 1 : 0;
         VL_HIP(hipMemcpyAsync(ws->mf_d_q64, ws->mf_h_q64, ((size_t)g * dim_ + g) * sizeof(double), hipMemcpyHostToDevice, st));
         if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
-        VL_HIP(launch_mfma_candidates(st, metric, d_slab16_, d_norm16_, d_sqnorm_, ws->mf_d_q64, g, n, (uint32_t)dim_,
+        VL_HIP(launch_mfma_candidates(st, metric, slab16, d_norm16_, d_sqnorm_, ws->mf_d_q64, g, n, (uint32_t)dim_,
                                       ws->mf, ws->mf_lists));
         if (prof) VL_HIP(hipEventRecord(ws->ev1, st));
         VL_HIP(launch_merge_finalize(st, metric, ws->mf_lists, 1, (int)g, d_master_, ws->mf_d_q64,

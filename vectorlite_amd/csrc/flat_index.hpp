@@ -168,7 +168,7 @@ private:
                       uint64_t* out_ids, double* out_scores, uint64_t* out_n, bool skip_fast) const;
     int run_exact(Workspace* ws, int metric, uint64_t n, uint64_t k_eff, std::vector<uint32_t>* pos,
                   std::vector<double>* scores) const;
-    int ensure_bf16_slab() const;            // lazily builds the bf16 slab the MFMA path streams
+    int ensure_bf16_slab(bool frag_major) const;  // lazily builds the bf16 slab (row-major, or MFMA fragment order) a filter streams
     int ensure_mfma_scratch(Workspace* ws) const;
     int search_batch_mfma(Workspace* ws, const double* queries, uint64_t nq, uint64_t k, uint64_t k_eff, int metric,
                           uint64_t* out_pos, uint64_t* out_ids, double* out_scores, uint64_t* out_n,
@@ -188,6 +188,8 @@ private:
     mutable float* d_norm16_ = nullptr;    // [cap] f32 |row| (the bf16 slab rows are unit-normalised)
     mutable float* d_sqnorm_ = nullptr;    // [cap] f32 |row|^2 for the GEMM-form Euclidean key (with d_slab16_)
     mutable uint64_t slab16_rows_ = 0;     // rows converted so far (== len() once built)
+    mutable void* d_slab16f_ = nullptr;    // the same rows in MFMA fragment order: what k_mfma_rows streams (lazy; dims <= 384)
+    mutable uint64_t slab16f_rows_ = 0;
     mutable std::mutex bf16_mu_;
     IngestStats* d_stats_ = nullptr;
     uint64_t cap_ = 0;

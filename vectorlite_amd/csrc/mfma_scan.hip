@@ -429,6 +429,329 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// K4r: the same filter with the operand roles of the memories swapped -- "row-stationary waves".
+//
+// k_mfma_scan above shares every ROW tile between its 8 waves through LDS and keeps the QUERIES in registers:
+// that costs a workgroup barrier, an LDS staging write and a common epilogue phase per tile, and the 8 waves
+// meet at every barrier -- both waves of a SIMD run their epilogue at the same time and the matrix pipe idles
+// (round 1: MFMA busy 48 %, waves parked 46 % of their cycles).  Here the 128 QUERIES of a workgroup sit in LDS
+// for the whole launch (one barrier, at the start) and every wave streams ITS OWN 32-row blocks straight from
+// global memory into MFMA A-fragment registers.  Waves never wait for each other: no per-tile barrier, no staging
+// write, no partial-sum exchange, and the two waves of a SIMD drift apart, so one wave's epilogue (VALU) runs under
+// the other's MFMAs.
+//
+//   per wave and 32-row block: A = 2 row blocks of 16 x K, held in 2 * K/32 fragment registers (bf16x8 each),
+//   loaded by one 16-byte global load per fragment; the block's two HALVES (64 queries = 4 query blocks each) reuse
+//   them; in the second half every fragment is reloaded for the wave's NEXT block right after its last use, so a
+//   load has a whole half (~1500-3000 cycles) to land: a rolling register window, no second buffer.
+//   B = query fragments, ds_read_b128 from the padded LDS image (conflict-free like the row tiles above), read
+//   B_AHEAD K-steps ahead of the MFMAs that consume them; each feeds 2 MFMAs (the two row blocks).
+//   LDS read traffic per flop equals k_mfma_scan's (one 1 KB fragment per 2 MFMAs = half the LDS rate).
+//   L2 -> CU traffic per flop doubles (128 instead of 256 queries per workgroup share a row): 1/128 B/flop,
+//   ~11 TB/s chip-wide at 1.4 PFLOP/s, served by the XCD L2s (the query chunks of one row range are co-resident
+//   on one XCD and walk the same blocks); HBM still sees every row once per launch.
+// Candidates go to the wave's own LDS ring segment (ballot + mbcnt, as above) and are flushed by the wave itself.
+// ---------------------------------------------------------------------------------------------
+#ifndef RS_NWAVES_OVERRIDE
+#define RS_NWAVES_OVERRIDE 8
+#endif
+constexpr int RS_NWAVES = RS_NWAVES_OVERRIDE;
+constexpr int RS_QPB = 128;        // queries per workgroup: 8 query blocks of 16
+constexpr int RS_SEG = 192;        // ring entries per wave
+
+template <int KSTEPS, int MODE, int METRIC>
+__global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __restrict__ slab16,
+                                                              const float* __restrict__ row_nrm,
+                                                              const float* __restrict__ row_sqn,
+                                                              const __bf16* __restrict__ q16, uint32_t nq,
+                                                              uint32_t blk_begin, uint32_t blk_end, uint32_t n_rows,
+                                                              int* __restrict__ gmax, uint32_t n_groups,
+                                                              const float* __restrict__ thr, Cand32* __restrict__ cand,
+                                                              uint32_t* __restrict__ cnt, uint32_t cap)
+{
+    constexpr int LDB = KSTEPS * 16;
+    constexpr int ROW_BYTES = LDB * 2;
+    constexpr int LDS_ROW = ROW_BYTES + 32;   // same padding as k_mfma_scan's row tiles: conflict-free ds_read_b128
+    constexpr int KS32 = KSTEPS / 2;          // K = 32 per MFMA
+    constexpr int NT = RS_NWAVES * 64;
+    constexpr int QB = RS_QPB / 16;           // 8 query blocks
+    constexpr int HQB = QB / 2;               // query blocks per half
+    constexpr int NPOS = 2 * KS32;            // (half, K-step) positions per row block
+    // K-steps the query fragments are read ahead of their MFMAs.  The fragment buffers rotate with the position,
+    // and the rotation must close over a row block (the loop over blocks re-enters at position 0): NB | NPOS.
+    constexpr int B_AHEAD = (NPOS % 3 == 0) ? 2 : 3;
+    constexpr int NB = B_AHEAD + 1;
+    static_assert(NPOS % NB == 0, "the fragment-buffer rotation closes over one row block");
+    static_assert(KSTEPS % 2 == 0, "whole 32-deep K steps");
+    constexpr int RING = (MODE == 1) ? RS_NWAVES * RS_SEG : 1;
+
+    __shared__ __attribute__((aligned(16))) unsigned char q_lds[RS_QPB * LDS_ROW];
+    __shared__ float ring_key[RING];
+    __shared__ uint32_t ring_pos[RING];
+    __shared__ unsigned short ring_q[RING];
+    __shared__ int gmax_lds[MODE == 0 ? RS_QPB : 1];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int c16 = lane & 15, kg = lane >> 4;
+    const uint32_t chunk_base = blockIdx.y * RS_QPB;
+
+    // ---- the workgroup's queries -> LDS (the only barrier of the kernel besides MODE 0's final combine) ----
+    {
+        constexpr int CPR = ROW_BYTES / 16;
+        constexpr int PIECES = RS_QPB * CPR;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(q16) + (size_t)chunk_base * ROW_BYTES;
+        for (int c = tid; c < PIECES; c += NT) {
+            const int r = c / CPR, cc = c % CPR;
+            *reinterpret_cast<u32x4*>(&q_lds[r * LDS_ROW + cc * 16]) = *reinterpret_cast<const u32x4*>(src + (size_t)c * 16);
+        }
+        if (MODE == 0 && tid < RS_QPB) gmax_lds[tid] = enc_f(-INFINITY);
+    }
+    __syncthreads();
+
+    float thr_q[QB], run_max[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const uint32_t qq = chunk_base + qb * 16 + c16;
+        thr_q[qb] = INFINITY;  // padding queries never pass
+        if (MODE == 1 && qq < nq) thr_q[qb] = thr[qq];
+#ifdef RS_DBG_NOCAND
+        thr_q[qb] = INFINITY;  // diagnostic: nothing ever passes
+#endif
+        run_max[qb] = -INFINITY;
+    }
+    uint32_t my_cnt = 0;
+
+    // block schedule: neighbouring WORKGROUPS stream neighbouring 32-row blocks (block = begin + x + gridDim.x * (wave + 8 i)),
+    // so in MODE 0 every workgroup (= group) owns rows as soon as there are gridDim.x blocks
+    const uint32_t stride = gridDim.x * RS_NWAVES;
+    uint32_t b = blk_begin + blockIdx.x + gridDim.x * (uint32_t)wave;
+    const bool has_work = b < blk_end;
+    const uint32_t b_last = has_work ? b + ((blk_end - 1 - b) / stride) * stride : blk_begin;  // a valid block to re-read at the tail
+
+    // The slab this kernel reads is FRAGMENT-MAJOR (k_rows_bf16_frag): per 16-row group and K-step one 1 KB chunk in
+    // lane order, so fragment (rb, s) of block blk is ONE contiguous 1 KB wave load (8 whole 128-byte lines) at
+    // blk * 32 rows + rb * 16 rows + s KB + 16 lane.  (With row-major rows every fragment load touched 16 half
+    // lines; at 128 queries per workgroup the L2 request rate, not the matrix pipe, then set the pace.)
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    auto a_ptr = [&](uint32_t blk) { return reinterpret_cast<const unsigned char*>(slab16) + (size_t)blk * (32 * ROW_BYTES) + lane_off; };
+    bf16x8 afrag[2][KS32];
+    f32x4 aux[2] = {f32x4{1.f, 1.f, 1.f, 1.f}, f32x4{1.f, 1.f, 1.f, 1.f}};
+    f32x4 aux2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    auto load_aux = [&](uint32_t blk) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const uint32_t r0 = blk * 32 + 16 * rb + 4 * kg;
+            if (METRIC != COSINE) aux[rb] = *reinterpret_cast<const f32x4*>(row_nrm + r0);
+            if (METRIC == EUCLIDEAN) aux2[rb] = *reinterpret_cast<const f32x4*>(row_sqn + r0);
+        }
+    };
+    if (has_work) {
+        const unsigned char* p = a_ptr(b);
+#pragma unroll
+        for (int s = 0; s < KS32; ++s)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) afrag[rb][s] = *reinterpret_cast<const bf16x8*>(p + rb * (16 * ROW_BYTES) + s * 1024);
+        load_aux(b);
+    }
+
+    // query fragments: position i = (half, s) reads the 4 query blocks of `half` at K-step s
+    const unsigned char* qrow = &q_lds[c16 * LDS_ROW + kg * 16];
+    bf16x8 bq[NB][HQB];
+    auto read_b = [&](int i, bf16x8(&dst)[HQB]) {
+        const int half = (i / KS32) & 1, s = i % KS32;
+#pragma unroll
+        for (int j = 0; j < HQB; ++j)
+            dst[j] = *reinterpret_cast<const bf16x8*>(qrow + (half * HQB + j) * 16 * LDS_ROW + s * 64);
+    };
+#pragma unroll
+    for (int i = 0; i < B_AHEAD; ++i) read_b(i, bq[i % NB]);
+
+    auto flush_wave = [&]() {  // this wave's ring segment -> the per-query global buffers (the kernel's only atomics)
+        const uint32_t n_e = my_cnt < (uint32_t)RS_SEG ? my_cnt : (uint32_t)RS_SEG;
+        for (uint32_t e = lane; e < n_e; e += 64) {
+            const uint32_t idx = (uint32_t)wave * RS_SEG + e;
+            const uint32_t qq = chunk_base + ring_q[idx];
+            const uint32_t slot = atomicAdd(&cnt[qq], 1u);
+            if (slot < cap) {
+                Cand32 c;
+                c.key = ring_key[idx];
+                c.pos = ring_pos[idx];
+                cand[(size_t)qq * cap + slot] = c;
+            }
+        }
+        if (my_cnt > (uint32_t)RS_SEG) {  // the segment overflowed: candidates of any of the 128 queries may be lost -> host redoes them
+            for (uint32_t j = lane; j < (uint32_t)RS_QPB; j += 64)
+                if (chunk_base + j < nq) atomicAdd(&cnt[chunk_base + j], cap + 1u);
+        }
+        my_cnt = 0;
+    };
+
+#ifdef RS_STAGGER  // diagnostic: the second-dispatched half of the workgroup starts late (s_sleep counts 64 cycles)
+    if (wave >= RS_NWAVES / 2) __builtin_amdgcn_s_sleep(RS_STAGGER);
+#endif
+#ifdef RS_PRIO
+    if (wave >= RS_NWAVES / 2) __builtin_amdgcn_s_setprio(1);
+#endif
+    for (; b < blk_end; b += stride) {
+        const uint32_t nb_raw = b + stride;
+        const uint32_t nb = nb_raw < blk_end ? nb_raw : b_last;  // the tail re-reads a valid block; its values are never used
+        const unsigned char* pn = a_ptr(nb);
+        const uint32_t row0 = b * 32;
+        const bool partial = row0 + 32 > n_rows;  // wave-uniform
+#if defined(RS_DBG_NOLDS) || defined(RS_DBG_NOLOAD)  // diagnostic: the fragments are opaque per block (no hoisting of the MFMAs)
+#pragma unroll
+        for (int i2 = 0; i2 < NB; ++i2)
+#pragma unroll
+            for (int j2 = 0; j2 < HQB; ++j2) asm volatile("" : "+v"(bq[i2][j2]));
+#pragma unroll
+        for (int s2 = 0; s2 < KS32; ++s2) {
+            asm volatile("" : "+v"(afrag[0][s2]));
+            asm volatile("" : "+v"(afrag[1][s2]));
+        }
+#endif
+        f32x4 aux_c[2], aux2_c[2];                 // this block's per-row scalars (the registers are reloaded below)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            aux_c[rb] = (METRIC != COSINE) ? aux[rb] : f32x4{1.f, 1.f, 1.f, 1.f};
+            aux2_c[rb] = (METRIC == EUCLIDEAN) ? aux2[rb] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 acc[2][HQB];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int j = 0; j < HQB; ++j) acc[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS32; ++s) {
+                const int i = half * KS32 + s;
+#ifndef RS_DBG_NOLDS
+                read_b((i + B_AHEAD) % NPOS, bq[(i + B_AHEAD) % NB]);
+#endif
+#ifndef RS_INTERLEAVE_OFF
+                // An in-order wave pays the full issue time of every instruction that sits BETWEEN two MFMAs once the pipe
+                // has drained (measured: ~16 cycles per ds_read_b128, ~50 per global load, and the partner wave of the
+                // SIMD runs in lockstep, so nobody fills the hole).  One memory instruction right behind each MFMA hides
+                // in that MFMA's 16 cycles instead: MFMA, ds_read, MFMA, ds_read, ... MFMA, global_load, ...
+#else
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+                for (int j = 0; j < HQB; ++j)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+                        acc[rb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[rb][s], bq[i % NB][j], acc[rb][j], 0, 0, 0);
+#ifndef RS_DBG_NOLOAD
+                if (half == 1) {  // last use of this K-step's row fragments: refill them for the wave's next block
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+                        afrag[rb][s] = *reinterpret_cast<const bf16x8*>(pn + rb * (16 * ROW_BYTES) + s * 1024);
+                    if (s == KS32 - 1) load_aux(nb);
+                }
+#endif
+#ifndef RS_INTERLEAVE_OFF
+#pragma unroll
+                for (int g = 0; g < HQB; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                }
+                if (half == 1) {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * HQB - HQB - 2, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * HQB - HQB, 0);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#ifdef RS_DBG_NOEPI  // diagnostic build: keep the accumulators alive with one add per half, nothing else
+            {
+                float keep = 0.f;
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int j = 0; j < HQB; ++j) keep += acc[rb][j][0] + acc[rb][j][1] + acc[rb][j][2] + acc[rb][j][3];
+                run_max[half] += keep;
+            }
+            if (false)
+#endif
+            // ---- epilogue of this half: C layout of a 16x16 block: column = lane & 15 (query), row = 4 (lane >> 4) + reg ----
+#pragma unroll
+            for (int j = 0; j < HQB; ++j) {
+                const int qb = half * HQB + j;
+                float keys[8];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        float key = acc[rb][j][jj];                                                   // cosine: x^.q
+                        if (METRIC == DOT) key *= aux_c[rb][jj];                                      // x.q
+                        if (METRIC == EUCLIDEAN) key = 2.0f * key * aux_c[rb][jj] - aux2_c[rb][jj];   // |q|^2 - |x - q|^2
+                        if (partial && row0 + (uint32_t)(16 * rb + 4 * kg + jj) >= n_rows) key = -INFINITY;
+                        keys[4 * rb + jj] = key;
+                    }
+                const float m0 = fmaxf(fmaxf(keys[0], keys[1]), fmaxf(keys[2], keys[3]));
+                const float m1 = fmaxf(fmaxf(keys[4], keys[5]), fmaxf(keys[6], keys[7]));
+                const float m = fmaxf(m0, m1);
+                const float tq = thr_q[qb];
+                if (MODE == 0) {
+                    run_max[qb] = fmaxf(run_max[qb], m);
+                } else if (__builtin_amdgcn_ballot_w64(m >= tq) != 0ull) {  // rare; only THIS wave pays for it
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) {
+                        if (__builtin_amdgcn_ballot_w64((rb ? m1 : m0) >= tq) == 0ull) continue;  // wave-uniform
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const float key = keys[4 * rb + jj];
+                            const bool is_cand = key >= tq && key > -INFINITY;  // masked rows are -inf; T_q may be too
+                            const unsigned long long mk = __builtin_amdgcn_ballot_w64(is_cand);
+                            if (mk != 0ull) {  // wave-uniform
+                                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32),
+                                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                                const uint32_t slot = my_cnt + rank;
+                                if (is_cand && slot < (uint32_t)RS_SEG) {
+                                    const uint32_t e = (uint32_t)wave * RS_SEG + slot;
+                                    ring_key[e] = key;
+                                    ring_pos[e] = row0 + (uint32_t)(16 * rb + 4 * kg + jj);
+                                    ring_q[e] = (unsigned short)(qb * 16 + c16);
+                                }
+                                my_cnt += (uint32_t)__popcll(mk);
+                            }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (MODE == 1 && my_cnt >= (uint32_t)(RS_SEG / 2)) flush_wave();  // wave-uniform
+    }
+#ifdef RS_DBG_NOEPI
+    if (run_max[0] + run_max[1] == 12345.678f) my_cnt = 1;  // diagnostic build: the sums above stay live
+#endif
+    if (MODE == 1) {
+        if (my_cnt) flush_wave();
+    } else {
+        // group maximum = max over every wave of the workgroup (its rows are held by no other group)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float mx = run_max[qb];  // the four k-groups of lanes saw different rows of one query
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            if (kg == 0) atomicMax(&gmax_lds[qb * 16 + c16], enc_f(mx));
+        }
+        __syncthreads();
+        if (tid < RS_QPB && chunk_base + tid < nq && blockIdx.x < n_groups)
+            gmax[(size_t)(chunk_base + tid) * n_groups + blockIdx.x] = gmax_lds[tid];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Single-query scan of the bf16 slab (opt-in candidate filter: half the HBM bytes of the f32 scan).
 // Same structure as k_scan (kernels.hip): G lanes share a row, 16-byte non-temporal loads straight to
 // registers (8 bf16 each), shuffle reduction, one sorted top-64 list per wave.  The query stays f32
@@ -638,6 +961,45 @@ __global__ __launch_bounds__(256) void k_rows_bf16(const double* __restrict__ ma
     }
 }
 
+// The same rows in FRAGMENT-MAJOR order for k_mfma_rows: row r, 16-byte piece p (8 bf16: columns 8 p .. 8 p + 7) goes to
+// byte (((r / 16) * (ldb / 32) + p / 4) * 64 + (p % 4) * 16 + r % 16) * 16 -- per 16-row group and 32-column K-step
+// one 1 KB chunk whose 64 pieces are in MFMA lane order (lane = 16 * (p % 4) + r % 16).  One wave per row.
+__global__ __launch_bounds__(256) void k_rows_bf16_frag(const double* __restrict__ master, uint64_t row0, uint64_t n,
+                                                        uint32_t dim, uint32_t ldb, unsigned char* __restrict__ out,
+                                                        float* __restrict__ out_nrm, float* __restrict__ out_sqn)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t n_waves = (uint64_t)gridDim.x * 4;
+    const uint32_t ks32 = ldb / 32;
+    for (uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += n_waves) {
+        const double* src = master + i * dim;
+        double ss = 0.0;
+        for (uint32_t c = lane; c < dim; c += 64) {
+            const double v = src[c];
+            ss += v * v;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+        const double nrm = sqrt(ss);
+        const double inv = nrm > 0.0 ? 1.0 / nrm : 0.0;
+        const uint64_t r = row0 + i;
+        for (uint32_t p = lane; p < ldb / 8; p += 64) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t c = 8 * p + e;
+                v[e] = (__bf16)(c < dim ? (float)(src[c] * inv) : 0.0f);
+            }
+            const size_t off = ((((size_t)(r >> 4) * ks32 + (p >> 2)) * 64) + (size_t)((p & 3) * 16 + (uint32_t)(r & 15))) * 16;
+            *reinterpret_cast<bf16x8*>(out + off) = v;
+        }
+        if (lane == 0) {
+            out_nrm[r] = (float)nrm;
+            out_sqn[r] = (float)ss;
+        }
+    }
+}
+
 }  // namespace
 
 #define VL_MFMA_KSTEPS(X) X(8) X(16) X(24) X(32) X(48)
@@ -688,6 +1050,24 @@ hipError_t launch_rows_bf16(hipStream_t s, const double* master, uint64_t n, uin
     const int grid = (int)std::min<uint64_t>((n + 3) / 4, 16384);
     hipLaunchKernelGGL(k_rows_bf16, dim3(grid), dim3(256), 0, s, master, n, dim, ldb, reinterpret_cast<__bf16*>(out_bf16),
                        out_norm, out_sqnorm);
+    return hipGetLastError();
+}
+
+bool mfma_rows_kernel(uint32_t dim)
+{
+    const char* kv = getenv("VL_MFMA_KERNEL");
+    return mfma_ldb(dim) <= 384 && !(kv && kv[0] == 't');
+}
+
+hipError_t launch_rows_bf16_frag(hipStream_t s, const double* master_rows, uint64_t row0, uint64_t n, uint32_t dim,
+                                 void* slab_frag_base, float* norm_base, float* sqnorm_base)
+{
+    if (n == 0) return hipSuccess;
+    const uint32_t ldb = mfma_ldb(dim);
+    if (ldb % 32 != 0) return hipErrorInvalidValue;
+    const int grid = (int)std::min<uint64_t>((n + 3) / 4, 16384);
+    hipLaunchKernelGGL(k_rows_bf16_frag, dim3(grid), dim3(256), 0, s, master_rows, row0, n, dim, ldb,
+                       reinterpret_cast<unsigned char*>(slab_frag_base), norm_base, sqnorm_base);
     return hipGetLastError();
 }
 
@@ -747,6 +1127,75 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
             stage_end[1] = (uint32_t)((uint64_t)n_tiles * 3 / 16);
             stage_end[2] = n_stages == 3 ? (uint32_t)((uint64_t)n_tiles * 7 / 16) : n_tiles;
             stage_end[3] = n_tiles;
+        }
+    }
+
+    // ---- row-stationary kernel (k_mfma_rows): every dimension up to 384; VL_MFMA_KERNEL=tile keeps the LDS-tile kernel ----
+    {
+        if (mfma_rows_kernel(dim)) {  // slab_bf16 is then the fragment-major slab (launch_rows_bf16_frag)
+            const uint32_t rq = (uint32_t)RS_QPB;
+            const uint32_t rnq_pad = (nq + rq - 1) / rq * rq;
+            if (rnq_pad > w.nq_cap) return hipErrorInvalidValue;
+            const uint32_t r_chunks = rnq_pad / rq;
+            {
+                const size_t total = (size_t)rnq_pad * ldb;
+                const int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
+                hipLaunchKernelGGL(k_queries_bf16, dim3(grid), dim3(256), 0, s, q64, nq, rnq_pad, dim, ldb, q16);
+            }
+            hipError_t e2 = hipMemsetAsync(w.cnt, 0, (size_t)rnq_pad * sizeof(uint32_t), s);
+            if (e2 != hipSuccess) return e2;
+            const uint32_t n_blocks = (uint32_t)((n_rows + 31) / 32);
+            // pass 0 over a sample of the blocks (>= 65536 rows or everything): one group per workgroup
+            uint32_t sample_blocks = n_blocks / 16;
+            const uint32_t min_blocks = std::min<uint32_t>(n_blocks, 65536u / 32u);
+            if (sample_blocks < min_blocks) sample_blocks = min_blocks;
+            const uint32_t r_groups = std::min<uint32_t>(sample_blocks, (uint32_t)MFMA_GROUPS);
+            const uint64_t r_sample_rows = std::min<uint64_t>((uint64_t)sample_blocks * 32, n_rows);
+            const uint32_t wg_cap = (uint32_t)env_grid(r_chunks);  // co-resident workgroups per query chunk
+            uint32_t st_end[4] = {0, n_blocks, n_blocks, n_blocks};
+            int r_stages = 1;
+            {
+                const char* se = getenv("VL_MFMA_STAGES");
+                const int want = se && *se ? atoi(se) : 3;
+                if (want >= 2 && n_blocks >= 128u * RS_NWAVES * wg_cap) {
+                    r_stages = want >= 3 ? 3 : 2;
+                    st_end[1] = (uint32_t)((uint64_t)n_blocks * 3 / 16);
+                    st_end[2] = r_stages == 3 ? (uint32_t)((uint64_t)n_blocks * 7 / 16) : n_blocks;
+                    st_end[3] = n_blocks;
+                }
+            }
+            bool r_launched = false;
+#define VL_RLAUNCH2(K, MET)                                                                                                     \
+    {                                                                                                                           \
+        hipLaunchKernelGGL((k_mfma_rows<K, 0, MET>), dim3(r_groups, r_chunks), dim3(RS_NWAVES * 64), 0, s, slab, row_norm,      \
+                           row_sqnorm, q16, nq, 0u, sample_blocks, (uint32_t)r_sample_rows, w.gmax, r_groups,                   \
+                           (const float*)nullptr, (Cand32*)nullptr, (uint32_t*)nullptr, 0u);                                    \
+        hipLaunchKernelGGL(k_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.gmax, r_groups, nq, q64 + (size_t)nq * dim,     \
+                           w.thr);                                                                                              \
+        for (int st = 0; st < r_stages; ++st) {                                                                                 \
+            const uint32_t tb = st_end[st], te = st_end[st + 1];                                                                \
+            const uint32_t gx = std::max<uint32_t>(1u, std::min<uint32_t>((te - tb + RS_NWAVES - 1) / RS_NWAVES, wg_cap));      \
+            hipLaunchKernelGGL((k_mfma_rows<K, 1, MET>), dim3(gx, r_chunks), dim3(RS_NWAVES * 64), 0, s, slab, row_norm,        \
+                               row_sqnorm, q16, nq, tb, te, (uint32_t)n_rows, (int*)nullptr, 0u, w.thr, w.cand, w.cnt,          \
+                               (uint32_t)MFMA_CAND_CAP);                                                                        \
+            if (st + 1 < r_stages)                                                                                              \
+                hipLaunchKernelGGL(k_refine_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.cand, w.cnt,                     \
+                                   (uint32_t)MFMA_CAND_CAP, nq, w.thr);                                                         \
+        }                                                                                                                       \
+        r_launched = true;                                                                                                      \
+    }
+#define VL_RLAUNCH(K)                                             \
+    if (!r_launched && ldb == (uint32_t)(K * 16)) {               \
+        if (metric == COSINE) VL_RLAUNCH2(K, COSINE)              \
+        else if (metric == EUCLIDEAN) VL_RLAUNCH2(K, EUCLIDEAN)   \
+        else VL_RLAUNCH2(K, DOT)                                  \
+    }
+            VL_RLAUNCH(8) VL_RLAUNCH(16) VL_RLAUNCH(24)
+#undef VL_RLAUNCH
+#undef VL_RLAUNCH2
+            if (!r_launched) return hipErrorInvalidValue;
+            hipLaunchKernelGGL(k_select_candidates, dim3(nq), dim3(256), 0, s, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, out_lists);
+            return hipGetLastError();
         }
     }
 

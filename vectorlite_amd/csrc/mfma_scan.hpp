@@ -48,6 +48,14 @@ bool mfma_scan_supported(uint32_t dim, int metric);
 hipError_t launch_rows_bf16(hipStream_t s, const double* master, uint64_t n, uint32_t dim, void* out_bf16,
                             float* out_norm, float* out_sqnorm);
 
+// Dimensions up to 384 (bf16 row stride <= 384) take the row-stationary kernel k_mfma_rows, which reads a FRAGMENT-MAJOR
+// bf16 slab (launch_rows_bf16_frag); VL_MFMA_KERNEL=tile keeps the LDS-tile kernel k_mfma_scan and its row-major slab.
+bool mfma_rows_kernel(uint32_t dim);
+// rows [row0, row0 + n) of the index (master_rows = their f64 rows) -> the fragment-major slab and the two per-row arrays,
+// all three addressed from their BASE (row 0): the layout interleaves 16 neighbouring rows
+hipError_t launch_rows_bf16_frag(hipStream_t s, const double* master_rows, uint64_t row0, uint64_t n, uint32_t dim,
+                                 void* slab_frag_base, float* norm_base, float* sqnorm_base);
+
 // rows per k_mfma_scan tile (its largest shape).  The bf16 slab and the two per-row arrays must be ALLOCATED in whole tiles
 // (ceil(n_rows / MFMA_TILE_ROWS) * MFMA_TILE_ROWS rows): the kernel fetches a tile as one contiguous block and masks
 // the rows past n_rows afterwards, whatever they hold.
@@ -55,7 +63,8 @@ constexpr uint32_t MFMA_TILE_ROWS = 64;
 
 // nq queries (f64 [nq, dim]) against the bf16 slab: writes one sorted top-64 candidate list per query
 // (out_lists[nq][64], the layout k_merge_finalize takes with n_lists = 1).
-// row_norm / row_sqnorm: the arrays launch_rows_bf16 wrote (dot and Euclidean keys need them).
+// slab_bf16: the row-major slab, or the fragment-major one when mfma_rows_kernel(dim).
+// row_norm / row_sqnorm: the arrays launch_rows_bf16 / launch_rows_bf16_frag wrote (dot and Euclidean keys need them).
 // q64: [nq, dim] f64 queries followed by their [nq] f64 norms (0 = answer on the exact path: no candidates are collected).
 hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf16, const float* row_norm,
                                   const float* row_sqnorm,
