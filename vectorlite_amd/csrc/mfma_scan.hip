@@ -459,6 +459,13 @@ constexpr int RS_NWAVES = RS_NWAVES_OVERRIDE;
 constexpr int RS_QPB = 128;        // queries per workgroup: 8 query blocks of 16
 constexpr int RS_SEG = 192;        // ring entries per wave
 
+__device__ __forceinline__ float max3f(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int KSTEPS, int MODE, int METRIC>
 __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __restrict__ slab16,
                                                               const float* __restrict__ row_nrm,
@@ -493,7 +500,8 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: block numbers, row bases
+                                                                // and the partial-block branch live in scalar registers
     const int c16 = lane & 15, kg = lane >> 4;
     const uint32_t chunk_base = blockIdx.y * RS_QPB;
 
@@ -682,51 +690,62 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
             if (false)
 #endif
             // ---- epilogue of this half: C layout of a 16x16 block: column = lane & 15 (query), row = 4 (lane >> 4) + reg ----
+            // Two copies selected by ONE wave-uniform branch: only the index's last block can hold rows past n_rows, and
+            // masking them costs a compare and two selects per key -- in every block, if it is written as a predicate.
+            auto epilogue = [&](auto partial_tag) {
+                constexpr bool PARTIAL = decltype(partial_tag)::value;
 #pragma unroll
-            for (int j = 0; j < HQB; ++j) {
-                const int qb = half * HQB + j;
-                float keys[8];
+                for (int j = 0; j < HQB; ++j) {
+                    const int qb = half * HQB + j;
+                    float keys[8];
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        float key = acc[rb][j][jj];                                                   // cosine: x^.q
-                        if (METRIC == DOT) key *= aux_c[rb][jj];                                      // x.q
-                        if (METRIC == EUCLIDEAN) key = 2.0f * key * aux_c[rb][jj] - aux2_c[rb][jj];   // |q|^2 - |x - q|^2
-                        if (partial && row0 + (uint32_t)(16 * rb + 4 * kg + jj) >= n_rows) key = -INFINITY;
-                        keys[4 * rb + jj] = key;
-                    }
-                const float m0 = fmaxf(fmaxf(keys[0], keys[1]), fmaxf(keys[2], keys[3]));
-                const float m1 = fmaxf(fmaxf(keys[4], keys[5]), fmaxf(keys[6], keys[7]));
-                const float m = fmaxf(m0, m1);
-                const float tq = thr_q[qb];
-                if (MODE == 0) {
-                    run_max[qb] = fmaxf(run_max[qb], m);
-                } else if (__builtin_amdgcn_ballot_w64(m >= tq) != 0ull) {  // rare; only THIS wave pays for it
-#pragma unroll
-                    for (int rb = 0; rb < 2; ++rb) {
-                        if (__builtin_amdgcn_ballot_w64((rb ? m1 : m0) >= tq) == 0ull) continue;  // wave-uniform
+                    for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) {
-                            const float key = keys[4 * rb + jj];
-                            const bool is_cand = key >= tq && key > -INFINITY;  // masked rows are -inf; T_q may be too
-                            const unsigned long long mk = __builtin_amdgcn_ballot_w64(is_cand);
-                            if (mk != 0ull) {  // wave-uniform
-                                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32),
-                                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                                const uint32_t slot = my_cnt + rank;
-                                if (is_cand && slot < (uint32_t)RS_SEG) {
-                                    const uint32_t e = (uint32_t)wave * RS_SEG + slot;
-                                    ring_key[e] = key;
-                                    ring_pos[e] = row0 + (uint32_t)(16 * rb + 4 * kg + jj);
-                                    ring_q[e] = (unsigned short)(qb * 16 + c16);
+                            float key = acc[rb][j][jj];                                                   // cosine: x^.q
+                            if (METRIC == DOT) key *= aux_c[rb][jj];                                      // x.q
+                            if (METRIC == EUCLIDEAN) key = 2.0f * key * aux_c[rb][jj] - aux2_c[rb][jj];   // |q|^2 - |x - q|^2
+                            if (PARTIAL && row0 + (uint32_t)(16 * rb + 4 * kg + jj) >= n_rows) key = -INFINITY;
+                            keys[4 * rb + jj] = key;
+                        }
+                    // max of the 8 keys in 4 instructions (fmaxf() costs a canonicalising v_max x, x per operand in IEEE
+                    // mode; the keys are MFMA sums of finite bf16 products)
+                    const float m = max3f(max3f(keys[0], keys[1], keys[2]), max3f(keys[3], keys[4], keys[5]), max3f(keys[6], keys[7], keys[7]));
+                    const float tq = thr_q[qb];
+                    if (MODE == 0) {
+                        run_max[qb] = max3f(run_max[qb], m, m);
+                    } else if (__builtin_amdgcn_ballot_w64(m >= tq) != 0ull) {  // rare; only THIS wave pays for it
+                        const float m0 = fmaxf(fmaxf(keys[0], keys[1]), fmaxf(keys[2], keys[3]));
+                        const float m1 = fmaxf(fmaxf(keys[4], keys[5]), fmaxf(keys[6], keys[7]));
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb) {
+                            if (__builtin_amdgcn_ballot_w64((rb ? m1 : m0) >= tq) == 0ull) continue;  // wave-uniform
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) {
+                                const float key = keys[4 * rb + jj];
+                                const bool is_cand = key >= tq && key > -INFINITY;  // masked rows are -inf; T_q may be too
+                                const unsigned long long mk = __builtin_amdgcn_ballot_w64(is_cand);
+                                if (mk != 0ull) {  // wave-uniform
+                                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32),
+                                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                                    const uint32_t slot = my_cnt + rank;
+                                    if (is_cand && slot < (uint32_t)RS_SEG) {
+                                        const uint32_t e = (uint32_t)wave * RS_SEG + slot;
+                                        ring_key[e] = key;
+                                        ring_pos[e] = row0 + (uint32_t)(16 * rb + 4 * kg + jj);
+                                        ring_q[e] = (unsigned short)(qb * 16 + c16);
+                                    }
+                                    my_cnt += (uint32_t)__popcll(mk);
                                 }
-                                my_cnt += (uint32_t)__popcll(mk);
                             }
                         }
                     }
                 }
-            }
+            };
+            if (partial)
+                epilogue(std::true_type{});
+            else
+                epilogue(std::false_type{});
             __builtin_amdgcn_sched_barrier(0);
         }
         if (MODE == 1 && my_cnt >= (uint32_t)(RS_SEG / 2)) flush_wave();  // wave-uniform
@@ -1146,7 +1165,9 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
             if (e2 != hipSuccess) return e2;
             const uint32_t n_blocks = (uint32_t)((n_rows + 31) / 32);
             // pass 0 over a sample of the blocks (>= 65536 rows or everything): one group per workgroup
-            uint32_t sample_blocks = n_blocks / 16;
+            const char* sd = getenv("VL_MFMA_SAMPLE_DIV");
+            const uint32_t sample_div = sd && *sd && atoi(sd) > 0 ? (uint32_t)atoi(sd) : 32u;
+            uint32_t sample_blocks = n_blocks / sample_div;
             const uint32_t min_blocks = std::min<uint32_t>(n_blocks, 65536u / 32u);
             if (sample_blocks < min_blocks) sample_blocks = min_blocks;
             const uint32_t r_groups = std::min<uint32_t>(sample_blocks, (uint32_t)MFMA_GROUPS);
