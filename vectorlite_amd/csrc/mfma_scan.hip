@@ -44,6 +44,15 @@ __device__ __forceinline__ int enc_f(float f)
 }
 __device__ __forceinline__ float dec_f(int e) { return __int_as_float(e >= 0 ? e : e ^ 0x7FFFFFFF); }
 
+// max of three finite floats in one instruction (fmaxf() costs a canonicalising v_max x, x per operand in IEEE mode;
+// the operands here are MFMA sums of finite bf16 products, or -inf)
+__device__ __forceinline__ float max3f(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int KSTEPS, int MODE, int METRIC, int NWAVES, int QT, int KSPLIT = 1, int SUB = 1>
 __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restrict__ slab16,
                                                    const float* __restrict__ row_nrm,
@@ -317,60 +326,68 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
                 for (int rb = 0; rb < NRB; ++rb) aux2[rb] = *reinterpret_cast<const f32x4*>(&sqn_lds[buf][rbase + 16 * rb + 4 * kg]);
             }
             const bool partial = row0 + TR > n_rows || !tile_live;  // partial last tile / repeated tail tile (wave-uniform)
+            // Two copies of the epilogue behind ONE branch: written as a predicate the row mask costs a compare and two
+            // selects per key in every tile, and only the index's last tile (or the repeated tail tile) needs it.
+            auto epilogue = [&](auto partial_tag) {
+                constexpr bool PARTIAL = decltype(partial_tag)::value;
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
+                for (int qt = 0; qt < QT; ++qt) {
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-                    float keys[4 * NRB];  // rows rbase + 16 rb + 4 kg + jj
-#pragma unroll
-                    for (int rb = 0; rb < NRB; ++rb) {
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            float key = acc[qt][rb][qb][jj];                                       // cosine: x^.q
-                            if (METRIC == DOT) key *= aux[rb][jj];                                 // x.q
-                            if (METRIC == EUCLIDEAN) key = 2.0f * key * aux[rb][jj] - aux2[rb][jj];  // |q|^2 - |x - q|^2
-                            if (partial && (!tile_live || row0 + (uint32_t)(rbase + 16 * rb + 4 * kg + jj) >= n_rows)) key = -INFINITY;
-                            keys[4 * rb + jj] = key;
-                        }
-                    }
-                    float m2[NRB];
-#pragma unroll
-                    for (int rb = 0; rb < NRB; ++rb)
-                        m2[rb] = fmaxf(fmaxf(keys[4 * rb], keys[4 * rb + 1]), fmaxf(keys[4 * rb + 2], keys[4 * rb + 3]));
-                    const float m = NRB == 2 ? fmaxf(m2[0], m2[NRB - 1]) : m2[0];
-                    const float tq = thr_q[qt][qb];
-                    if (MODE == 0) {
-                        run_max[qt][qb] = fmaxf(run_max[qt][qb], m);
-                    } else if (__builtin_amdgcn_ballot_w64(m >= tq) != 0ull) {
-                        // Rare per wave-tile, but the WHOLE workgroup waits for the slowest wave at the next
-                        // barrier, and with 8 waves some wave takes this branch on most tiles: it must be
-                        // short.  No atomic (the wave appends to its own ring segment), register groups without a
-                        // candidate are skipped with one ballot, slots come from ballot + mbcnt.
+                    for (int qb = 0; qb < 2; ++qb) {
+                        float keys[4 * NRB];  // rows rbase + 16 rb + 4 kg + jj
 #pragma unroll
                         for (int rb = 0; rb < NRB; ++rb) {
-                            if (__builtin_amdgcn_ballot_w64(m2[rb] >= tq) == 0ull) continue;  // wave-uniform
 #pragma unroll
                             for (int jj = 0; jj < 4; ++jj) {
-                                const float key = keys[4 * rb + jj];
-                                const bool is_cand = key >= tq && key > -INFINITY;  // masked rows are -inf; T_q may be too
-                                const unsigned long long mk = __builtin_amdgcn_ballot_w64(is_cand);
-                                if (mk != 0ull) {  // wave-uniform
-                                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32),
-                                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                                    const uint32_t slot = my_cnt + rank;
-                                    if (is_cand && slot < (uint32_t)SEG) {
-                                        const uint32_t e = (uint32_t)wave * SEG + slot;
-                                        ring_key[e] = key;
-                                        ring_pos[e] = row0 + (uint32_t)(rbase + 16 * rb + 4 * kg + jj);
-                                        ring_q[e] = (unsigned short)((qwave * QT + qt) * 32 + qb * 16 + c16);
+                                float key = acc[qt][rb][qb][jj];                                       // cosine: x^.q
+                                if (METRIC == DOT) key *= aux[rb][jj];                                 // x.q
+                                if (METRIC == EUCLIDEAN) key = 2.0f * key * aux[rb][jj] - aux2[rb][jj];  // |q|^2 - |x - q|^2
+                                if (PARTIAL && (!tile_live || row0 + (uint32_t)(rbase + 16 * rb + 4 * kg + jj) >= n_rows)) key = -INFINITY;
+                                keys[4 * rb + jj] = key;
+                            }
+                        }
+                        float m2[NRB];
+#pragma unroll
+                        for (int rb = 0; rb < NRB; ++rb) m2[rb] = max3f(max3f(keys[4 * rb], keys[4 * rb + 1], keys[4 * rb + 2]), keys[4 * rb + 3], keys[4 * rb + 3]);
+                        const float m = NRB == 2 ? max3f(m2[0], m2[NRB - 1], m2[0]) : m2[0];
+                        const float tq = thr_q[qt][qb];
+                        if (MODE == 0) {
+                            run_max[qt][qb] = max3f(run_max[qt][qb], m, m);
+                        } else if (__builtin_amdgcn_ballot_w64(m >= tq) != 0ull) {
+                            // Rare per wave-tile, but the WHOLE workgroup waits for the slowest wave at the next
+                            // barrier, and with 8 waves some wave takes this branch on most tiles: it must be
+                            // short.  No atomic (the wave appends to its own ring segment), register groups without a
+                            // candidate are skipped with one ballot, slots come from ballot + mbcnt.
+#pragma unroll
+                            for (int rb = 0; rb < NRB; ++rb) {
+                                if (__builtin_amdgcn_ballot_w64(m2[rb] >= tq) == 0ull) continue;  // wave-uniform
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj) {
+                                    const float key = keys[4 * rb + jj];
+                                    const bool is_cand = key >= tq && key > -INFINITY;  // masked rows are -inf; T_q may be too
+                                    const unsigned long long mk = __builtin_amdgcn_ballot_w64(is_cand);
+                                    if (mk != 0ull) {  // wave-uniform
+                                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32),
+                                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                                        const uint32_t slot = my_cnt + rank;
+                                        if (is_cand && slot < (uint32_t)SEG) {
+                                            const uint32_t e = (uint32_t)wave * SEG + slot;
+                                            ring_key[e] = key;
+                                            ring_pos[e] = row0 + (uint32_t)(rbase + 16 * rb + 4 * kg + jj);
+                                            ring_q[e] = (unsigned short)((qwave * QT + qt) * 32 + qb * 16 + c16);
+                                        }
+                                        my_cnt += (uint32_t)__popcll(mk);
                                     }
-                                    my_cnt += (uint32_t)__popcll(mk);
                                 }
                             }
                         }
                     }
                 }
-            }
+            };
+            if (partial)
+                epilogue(std::true_type{});
+            else
+                epilogue(std::false_type{});
             __builtin_amdgcn_sched_barrier(0);  // keep the sub-tiles' epilogues apart (see below)
             }  // sub
             if (NBUF == 1) __syncthreads();  // single buffer: everyone is done reading before the next write
@@ -459,12 +476,6 @@ constexpr int RS_NWAVES = RS_NWAVES_OVERRIDE;
 constexpr int RS_QPB = 128;        // queries per workgroup: 8 query blocks of 16
 constexpr int RS_SEG = 192;        // ring entries per wave
 
-__device__ __forceinline__ float max3f(float a, float b, float c)
-{
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
 
 template <int KSTEPS, int MODE, int METRIC>
 __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __restrict__ slab16,
@@ -1180,8 +1191,11 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
                 const int want = se && *se ? atoi(se) : 3;
                 if (want >= 2 && n_blocks >= 128u * RS_NWAVES * wg_cap) {
                     r_stages = want >= 3 ? 3 : 2;
-                    st_end[1] = (uint32_t)((uint64_t)n_blocks * 3 / 16);
-                    st_end[2] = r_stages == 3 ? (uint32_t)((uint64_t)n_blocks * 7 / 16) : n_blocks;
+                    const char* s1 = getenv("VL_MFMA_STAGE1");
+                    const char* s2 = getenv("VL_MFMA_STAGE2");
+                    const uint32_t f1 = s1 && *s1 ? (uint32_t)atoi(s1) : 3u, f2 = s2 && *s2 ? (uint32_t)atoi(s2) : 7u;  // sixteenths
+                    st_end[1] = (uint32_t)((uint64_t)n_blocks * f1 / 16);
+                    st_end[2] = r_stages == 3 ? (uint32_t)((uint64_t)n_blocks * f2 / 16) : n_blocks;
                     st_end[3] = n_blocks;
                 }
             }
