@@ -9,11 +9,26 @@ per-kernel counter averages.  Kernel names are shortened to the function name + 
 """
 import re
 import sqlite3
+import subprocess
 import sys
 
 
+_dm = {}
+
+
+def demangle(name: str) -> str:
+    if not name.startswith("_Z"):
+        return name
+    if name not in _dm:
+        try:
+            _dm[name] = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name
+        except Exception:
+            _dm[name] = name
+    return _dm[name]
+
+
 def short(name: str) -> str:
-    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"\(anonymous namespace\)::", "", demangle(name))
     m = re.match(r"(?:void\s+)?([\w:]+(?:<[^()]*?>)?)\(", name)
     s = m.group(1) if m else name
     return s if len(s) <= 120 else s[:117] + "..."
@@ -43,7 +58,10 @@ def pmc(db):
         a[0] += 1
         a[1] += value
     print("kernel,counter,dispatches,avg_value,avg_value_x2_KB_to_bytes_gfx950")
-    for (k, cn), a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    for (k, cn), a in sorted(agg.items(), key=lambda kv: (kv[0][0], kv[0][1])):
+        if only and only not in k:
+            continue
         avg = a[1] / a[0]
         # MI355X_MICROARCH.md, HBM/rocprofv3 section: FETCH_SIZE / WRITE_SIZE are in KB and read 2x low on gfx950
         corr = f"{avg * 1024 * 2:.0f}" if cn in ("FETCH_SIZE", "WRITE_SIZE") else ""
