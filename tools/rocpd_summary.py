@@ -27,7 +27,17 @@ def demangle(name: str) -> str:
     return _dm[name]
 
 
+def itanium_fallback(name: str) -> str:
+    """c++filt does not know the bf16 type code (DF16b): render `11k_mfma_rowsILi24ELi1ELi0EE...` as k_mfma_rows<24, 1, 0>."""
+    m = re.search(r"\d+(k_\w+?)I((?:Li\d+E)+)E", name)
+    if not m:
+        return name
+    return "vl::" + m.group(1) + "<" + ", ".join(re.findall(r"Li(\d+)E", m.group(2))) + ">("
+
+
 def short(name: str) -> str:
+    if name.startswith("_Z") and demangle(name).startswith("_Z"):
+        name = itanium_fallback(name)
     name = re.sub(r"\(anonymous namespace\)::", "", demangle(name))
     m = re.match(r"(?:void\s+)?([\w:]+(?:<[^()]*?>)?)\(", name)
     s = m.group(1) if m else name
