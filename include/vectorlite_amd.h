@@ -151,9 +151,27 @@ int vl_index_type(const vl_index *h);
 int vl_index_metric(const vl_index *h, int *out_metric);
 
 /* HNSW only, own extension (the reference has no ef knob): nq walks with beam width
- * max(ef, min(k, len)); outputs as vl_index_search_batch. */
+ * max(ef, min(k, len)); outputs as vl_index_search_batch.  ef = 0 is what vl_index_search does: the reference's
+ * ef = min(k, len) (src/index/hnsw.rs:437,454) raised to the handle's beam floor (below). */
 int vl_index_search_ef(const vl_index *h, const double *queries, uint64_t nq, uint64_t q_len, uint64_t k,
                        uint32_t ef, int metric, uint64_t *out_ids, double *out_scores, uint64_t *out_n);
+
+/* HNSW handle: beam floor of searches that name no ef.  The reference walks with ef = min(k, len) -- 10 entries for
+ * k = 10; this library's walk keeps at least `min_beam` entries (default 32, at most 128) and returns the best
+ * min(k, len) of them: the same number of results, recall@10 0.96 instead of 0.78 at N = 1 M on embedding-like data.
+ * 0 = the strict reference rule. */
+int vl_index_hnsw_set_min_beam(vl_index *h, uint32_t min_beam);
+
+/* HNSW handle: the graph as it stands, every node (tombstoned ones included; node = insertion position).  level[n]
+ * = top layer of each node; layer 0: cnt0[n] neighbours of node i at nbr0[i * m0 ..]; layer L >= 1 of node i: slot
+ * upper_off[i] + L - 1 with cntU[slot] neighbours at nbrU[slot * m ..]; node_ids[n] the caller's ids, live[n] 0 for
+ * tombstones, rows[n, dim] the f64 rows.  Any output pointer may be NULL.  The reference cannot export its graph
+ * (crate hnsw 0.11.0 keeps it private; HNSWIndex::hnsw is #[serde(skip)], src/index/hnsw.rs:199-200); this is what a
+ * CPU-side walk of the SAME graph needs (the repository's checker, oracle/vl_hnsw_cpu.c, is one). */
+int vl_index_hnsw_graph_info(const vl_index *h, uint64_t *n_nodes, uint32_t *entry, int *max_level, uint32_t *m,
+                             uint32_t *m0, uint64_t *upper_slots);
+int vl_index_hnsw_graph_export(const vl_index *h, uint8_t *level, uint32_t *upper_off, uint32_t *cnt0, uint32_t *nbr0,
+                               uint32_t *cntU, uint32_t *nbrU, uint64_t *node_ids, uint8_t *live, double *rows);
 
 /* get_vector(id) (src/index/flat.rs:129-131): first row with that id -> out[dim];
  * VL_ERR_NOT_FOUND stands for None. */

@@ -34,8 +34,8 @@ _SO = os.path.join(_HERE, "libvl_oracle.so")
 
 def build(force: bool = False) -> str:
     """Compile the C restatement with gcc (oracle/Makefile)."""
-    src = os.path.join(_HERE, "vl_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("vl_oracle.c", "vl_hnsw_cpu.c", "vl_oracle.h")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(_SO) < os.path.getmtime(x) for x in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libvl_oracle.so"])
     return _SO
 
@@ -240,3 +240,35 @@ def py_flat_search(rows: List[Tuple[int, Sequence[float]]], query, k: int, metri
     scored.sort(key=lambda t: -t[0])
     top = scored[:k]
     return [t[2] for t in top], [t[0] for t in top]
+
+
+class HnswCpuWalker:
+    """The "CPU HNSW": single-threaded walks of a graph exported by vl_index_hnsw_graph_export, with the reference's
+    u64 distance callbacks (oracle/vl_hnsw_cpu.c).  `graph` is what vectorlite_amd.HNSWIndex.graph(with_rows=True)
+    returns.  Checker only."""
+
+    def __init__(self, graph, metric: int):
+        L = lib()
+        vp = C.c_void_p
+        L.vlo_hnsw_walk.restype = C.c_size_t
+        L.vlo_hnsw_walk.argtypes = [C.c_int, vp, C.c_size_t, C.c_size_t, vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32,
+                                    C.c_uint32, C.c_int, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]
+        self.L, self.g, self.metric = L, graph, int(metric)
+        self.rows = np.ascontiguousarray(graph["rows"], dtype=np.float64)
+        self.keep = {k: np.ascontiguousarray(graph[k]) for k in ("level", "upper_off", "cnt0", "nbr0", "cntU", "nbrU")}
+        self.stamp = np.zeros(max(graph["n"], 1), np.uint32)
+        self.epoch = C.c_uint32(0)
+        self.evals = C.c_uint64(0)
+
+    def search(self, q, ef: int, k: int):
+        """(nodes [<= k], u64 distances) in ascending distance."""
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        out_n = np.zeros(max(k, 1), np.uint32)
+        out_d = np.zeros(max(k, 1), np.uint64)
+        g, kp = self.g, self.keep
+        p = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+        got = self.L.vlo_hnsw_walk(self.metric, p(self.rows), self.rows.shape[1], g["n"], p(kp["level"]), p(kp["upper_off"]),
+                                   p(kp["cnt0"]), p(kp["nbr0"]), g["m0"], p(kp["cntU"]), p(kp["nbrU"]), g["m"], g["entry"],
+                                   g["max_level"], p(q), int(ef), int(k), p(self.stamp), C.byref(self.epoch), p(out_n),
+                                   p(out_d), C.byref(self.evals))
+        return out_n[:got].copy(), out_d[:got].copy()

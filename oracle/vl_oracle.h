@@ -85,4 +85,12 @@ size_t vlo_hnsw_postprocess(uint64_t *ids, const uint64_t *dists, double *scores
 #ifdef __cplusplus
 }
 #endif
+/* vl_hnsw_cpu.c: the "CPU HNSW" -- a single-threaded walk of an exported graph with the reference's u64 distances
+ * (graph walk of crate hnsw 0.11.0: parity unpinned; see the file's header). */
+size_t vlo_hnsw_walk(int metric, const double *rows, size_t dim, size_t n_nodes, const uint8_t *level,
+                     const uint32_t *upper_off, const uint32_t *cnt0, const uint32_t *nbr0, uint32_t m0,
+                     const uint32_t *cntU, const uint32_t *nbrU, uint32_t m, uint32_t entry, int max_level,
+                     const double *q, uint32_t ef, uint32_t k, uint32_t *stamp, uint32_t *epoch, uint32_t *out_nodes,
+                     uint64_t *out_dist, uint64_t *evals);
+
 #endif

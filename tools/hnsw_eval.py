@@ -53,6 +53,7 @@ def main():
     for ef in [int(e) for e in a.efs.split(",")]:
         hn.search_batch(Q[:8], 10, a.metric, ef=ef)
         q0, e0 = hn.walk_stats()
+        hn.set_min_beam(0 if ef == 10 else 32)  # ef = 10 is the reference's strict rule ef = min(k, len)
         t0 = time.perf_counter(); hi, hs, hnn = hn.search_batch(Q, 10, a.metric, ef=(0 if ef == 10 else ef)); dt = time.perf_counter() - t0
         q1, e1 = hn.walk_stats()
         evq = (e1 - e0) / max(q1 - q0, 1)

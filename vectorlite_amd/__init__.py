@@ -442,6 +442,35 @@ class HNSWIndex:
         _raise(self._L.vl_index_coalesce_stats(self._h, C.byref(b), C.byref(q)))
         return int(b.value), int(q.value)
 
+    def graph(self, with_rows: bool = False) -> Dict[str, Any]:
+        """The graph as it stands (vl_index_hnsw_graph_info / _export): entry, max_level, m, m0 and the arrays
+        level[n], upper_off[n], cnt0[n], nbr0[n, m0], cntU[slots], nbrU[slots, m], node_ids[n], live[n] (+ rows[n, dim])."""
+        n, slots = C.c_uint64(0), C.c_uint64(0)
+        entry, m, m0 = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        lvl = C.c_int(0)
+        _raise(self._L.vl_index_hnsw_graph_info(self._h, C.byref(n), C.byref(entry), C.byref(lvl), C.byref(m), C.byref(m0),
+                                                C.byref(slots)))
+        nn, ns, d = int(n.value), int(slots.value), self.dimension()
+        g = {"entry": int(entry.value), "max_level": int(lvl.value), "m": int(m.value), "m0": int(m0.value), "n": nn,
+             "level": np.zeros(max(nn, 1), np.uint8), "upper_off": np.zeros(max(nn, 1), np.uint32),
+             "cnt0": np.zeros(max(nn, 1), np.uint32), "nbr0": np.zeros((max(nn, 1), int(m0.value)), np.uint32),
+             "cntU": np.zeros(max(ns, 1), np.uint32), "nbrU": np.zeros((max(ns, 1), int(m.value)), np.uint32),
+             "node_ids": np.zeros(max(nn, 1), np.uint64), "live": np.zeros(max(nn, 1), np.uint8)}
+        rows = np.zeros((max(nn, 1), d), np.float64) if with_rows else None
+        vp = lambda a: C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p()  # noqa: E731
+        _raise(self._L.vl_index_hnsw_graph_export(self._h, vp(g["level"]), vp(g["upper_off"]), vp(g["cnt0"]), vp(g["nbr0"]),
+                                                  vp(g["cntU"]), vp(g["nbrU"]), vp(g["node_ids"]), vp(g["live"]), vp(rows)))
+        if with_rows:
+            g["rows"] = rows[:nn]
+        for key in ("level", "upper_off", "cnt0", "nbr0", "node_ids", "live"):
+            g[key] = g[key][:nn]
+        g["cntU"], g["nbrU"] = g["cntU"][:ns], g["nbrU"][:ns]
+        return g
+
+    def set_min_beam(self, min_beam: int) -> None:
+        """Beam floor of searches that name no ef (default 32); 0 = the reference's strict ef = min(k, len)."""
+        _raise(self._L.vl_index_hnsw_set_min_beam(self._h, int(min_beam)))
+
     def walk_stats(self) -> Tuple[int, int]:
         """(queries walked, distance evaluations made for them) since creation."""
         a, b = C.c_uint64(0), C.c_uint64(0)

@@ -24,6 +24,7 @@ SYMBOLS = [
     "vl_vlc_open", "vl_vlc_close", "vl_vlc_name", "vl_vlc_info", "vl_vlc_side_table", "vl_vlc_read_values", "vl_vlc_build_index",
     "vl_index_profile_enable", "vl_index_profile_read", "vl_runtime_info",
     "vl_comm_unique_id", "vl_comm_create", "vl_comm_destroy", "vl_comm_world", "vl_comm_rank",
+    "vl_index_hnsw_set_min_beam", "vl_index_hnsw_graph_info", "vl_index_hnsw_graph_export",
     "vl_shard_sync", "vl_shard_search_batch", "vl_shard_packed_words", "vl_shard_search_local", "vl_shard_merge",
 ]
 
@@ -96,6 +97,10 @@ def load() -> C.CDLL:
     sig("vl_index_set_coalescing", i32, [vp, i32, i32])
     sig("vl_index_coalesce_stats", i32, [vp, p_u64, p_u64])
     sig("vl_index_hnsw_walk_stats", i32, [vp, p_u64, p_u64])
+    sig("vl_index_hnsw_set_min_beam", i32, [vp, C.c_uint32])
+    p_u32 = C.POINTER(C.c_uint32)
+    sig("vl_index_hnsw_graph_info", i32, [vp, p_u64, p_u32, p_i32, p_u32, p_u32, p_u64])
+    sig("vl_index_hnsw_graph_export", i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp])
     sig("vl_index_profile_enable", i32, [vp, i32])
     sig("vl_index_profile_read", i32, [vp, p_u64, p_f64, p_u64])
     sig("vl_runtime_info", i32, [C.POINTER(C.c_int), C.POINTER(C.c_int)])

@@ -523,6 +523,39 @@ int vl_index_coalesce_stats(const vl_index* h, uint64_t* batches, uint64_t* quer
     return VL_OK;
 }
 
+int vl_index_hnsw_graph_info(const vl_index* h, uint64_t* n_nodes, uint32_t* entry, int* max_level, uint32_t* m,
+                             uint32_t* m0, uint64_t* upper_slots)
+{
+    if (!h || !h->hnsw) {
+        vl::set_last_error("this entry point needs an HNSW index handle");
+        return VL_ERR_INVALID_ARG;
+    }
+    h->hnsw->graph_info(n_nodes, entry, max_level, m, m0, upper_slots);
+    return VL_OK;
+}
+
+int vl_index_hnsw_graph_export(const vl_index* h, uint8_t* level, uint32_t* upper_off, uint32_t* cnt0, uint32_t* nbr0,
+                               uint32_t* cntU, uint32_t* nbrU, uint64_t* node_ids, uint8_t* live, double* rows)
+{
+    return guarded([&]() -> int {
+        if (!h || !h->hnsw) {
+            vl::set_last_error("this entry point needs an HNSW index handle");
+            return VL_ERR_INVALID_ARG;
+        }
+        return h->hnsw->graph_export(level, upper_off, cnt0, nbr0, cntU, nbrU, node_ids, live, rows);
+    });
+}
+
+int vl_index_hnsw_set_min_beam(vl_index* h, uint32_t min_beam)
+{
+    if (!h || !h->hnsw) {
+        vl::set_last_error("this entry point needs an HNSW index handle");
+        return VL_ERR_INVALID_ARG;
+    }
+    h->hnsw->set_min_beam(min_beam);
+    return VL_OK;
+}
+
 int vl_index_hnsw_walk_stats(const vl_index* h, uint64_t* queries, uint64_t* distance_evals)
 {
     if (!h || !h->hnsw) return VL_ERR_INVALID_ARG;

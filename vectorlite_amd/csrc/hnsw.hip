@@ -4,7 +4,8 @@
 //
 // One WAVE per query / per inserted node:
 //   * a hop loads the <= 32 neighbour ids of the expanded node with one coalesced load and filters them
-//     through a per-wave visited-stamp array in HBM;
+//     through the walk's own visited set: a bitmap over the nodes (one returning atomic-or per neighbour) plus a
+//     log of the nodes it set, so that the set is cleared in time proportional to the walk, not to the graph;
 //   * walks navigate by f32 distances (two lanes per neighbour on the flat scan's f32 slab: half the bytes
 //     and half the serial length of the f64 row; 3x lower single-query latency, 2x faster build);
 //   * a QUERY walk then gives every node of its final beam the reference's exact callback value -- one lane
@@ -169,11 +170,60 @@ __device__ __forceinline__ LayerView layer_of(const HnswGraphView& g, uint32_t n
     return lv;
 }
 
+// Visited set of ONE walk (one wave): N / 8 bytes of bitmap + a log of the nodes set, both in the walk scratch the
+// launch borrowed (hnsw_index.cpp: WalkScratch).  Nothing in it is shared with another walk, so any number of
+// walk kernels run at the same time, and it costs 1/32 of a u32 stamp per node.  All accesses to the bitmap are
+// L2 atomics (or / and), so their order is the wave's program order whichever lane issues them.
+struct Visited {
+    uint32_t* bits;
+    uint32_t* log;
+    uint32_t words, log_cap;
+    uint32_t n_log;  // wave-uniform; > log_cap = the log overflowed (clear() then wipes the whole bitmap)
+
+    __device__ __forceinline__ void attach(const HnswGraphView& g, uint32_t slot)
+    {
+        words = g.vis_words;
+        log_cap = g.vis_log_cap;
+        bits = g.vis_bits + (size_t)slot * words;
+        log = g.vis_log + (size_t)slot * log_cap;
+        n_log = 0;
+    }
+    // every lane may offer one node; true = this call marked it (it had not been visited)
+    __device__ __forceinline__ bool mark(uint32_t e, bool act)
+    {
+        const uint32_t bit = 1u << (e & 31u);
+        uint32_t old = bit;
+        if (act) old = atomicOr(&bits[e >> 5], bit);
+        const bool fresh = act && (old & bit) == 0u;
+        const unsigned long long mk = __ballot(fresh);
+        if (mk != 0ull) {  // wave-uniform
+            const uint32_t idx = n_log + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            if (fresh && idx < log_cap) log[idx] = e;
+            n_log += (uint32_t)__popcll(mk);
+        }
+        return fresh;
+    }
+    __device__ __forceinline__ void clear()
+    {
+        const int lane = lane_id();
+        if (n_log <= log_cap) {
+            for (uint32_t i = lane; i < n_log; i += 64) {
+                // agent-scope load: the entry was stored by another lane of this wave, the line may sit stale in this CU's L1
+                const uint32_t e = __hip_atomic_load(&log[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicAnd(&bits[e >> 5], 0u);
+            }
+        } else {
+            for (uint32_t w = lane; w < words; w += 64) atomicAnd(&bits[w], 0u);
+        }
+        n_log = 0;
+    }
+};
+
 // Beam search of width ef on one layer.  Precondition: L holds the entry points (unexpanded) and
-// their stamps are set.
+// they are marked in the visited set.
 template <int METRIC, int S>
-__device__ __forceinline__ void beam_layer(const HnswGraphView& g, const double* q, int layer, uint32_t* stamps,
-                                           uint32_t epoch, BeamList<S>& L, int ef, uint32_t* evals = nullptr)
+__device__ __forceinline__ void beam_layer(const HnswGraphView& g, const double* q, int layer, Visited& vis,
+                                           BeamList<S>& L, int ef, uint32_t* evals = nullptr)
 {
     const int lane = lane_id();
     for (;;) {
@@ -185,11 +235,7 @@ __device__ __forceinline__ void beam_layer(const HnswGraphView& g, const double*
         L.mark_expanded(idx);
         const LayerView lv = layer_of(g, c, layer);
         uint32_t e = (uint32_t)lane < lv.cnt ? lv.nbr[lane] : HNSW_NONE;
-        bool act = e != HNSW_NONE;
-        if (act) {
-            if (stamps[e] == epoch) act = false;
-            else stamps[e] = epoch;
-        }
+        const bool act = vis.mark(e, e != HNSW_NONE);
         unsigned long long de = ~0ull;
         if (act) de = row_distance<METRIC>(g.master + (size_t)e * g.dim, q, g.dim);
         if (evals) *evals += (uint32_t)__popcll(__ballot(act));  // wave-uniform count of rows walked
@@ -267,7 +313,7 @@ __device__ __forceinline__ unsigned long long row_distance_f32(const HnswGraphVi
 // (rounds of 32 neighbours when a list is longer).
 template <int METRIC, int S>
 __device__ __forceinline__ void beam_layer_f32(const HnswGraphView& g, const float* q32, float q_inv, int layer,
-                                               uint32_t* stamps, uint32_t epoch, BeamList<S>& L, int ef, uint32_t* evals)
+                                               Visited& vis, BeamList<S>& L, int ef, uint32_t* evals)
 {
     const int lane = lane_id();
     const int half = lane >> 5, nl = lane & 31;
@@ -281,11 +327,7 @@ __device__ __forceinline__ void beam_layer_f32(const HnswGraphView& g, const flo
         const LayerView lv = layer_of(g, c, layer);
         for (uint32_t base = 0; base < lv.cnt; base += 32) {
             uint32_t e = base + (uint32_t)nl < lv.cnt ? lv.nbr[base + nl] : HNSW_NONE;
-            bool act = e != HNSW_NONE;
-            if (act && half == 0) {
-                if (stamps[e] == epoch) act = false;
-                else stamps[e] = epoch;
-            }
+            bool act = vis.mark(e, e != HNSW_NONE && half == 0);
             act = __shfl((int)act, nl) != 0;  // the upper half-wave follows its partner's visited check
             unsigned long long de = ~0ull;
             if (act) de = row_distance_f32<METRIC>(g, e, q32, q_inv, half);
@@ -303,15 +345,14 @@ __device__ __forceinline__ void beam_layer_f32(const HnswGraphView& g, const flo
     }
 }
 
-// Move to the next layer: keep the entries as entry points, fresh visited epoch.
+// Move to the next layer: keep the entries as entry points, fresh visited set (only they are marked).
 template <int S>
-__device__ __forceinline__ void next_layer(BeamList<S>& L, uint32_t* stamps, uint32_t& epoch)
+__device__ __forceinline__ void next_layer(BeamList<S>& L, Visited& vis)
 {
-    epoch += 1;
+    vis.clear();
     L.reopen();
 #pragma unroll
-    for (int s = 0; s < S; ++s)
-        if (L.v[s] != HNSW_NONE) stamps[L.v[s] & ~EXPANDED] = epoch;
+    for (int s = 0; s < S; ++s) (void)vis.mark(L.v[s] & ~EXPANDED, L.v[s] != HNSW_NONE);
 }
 
 // convert_distance_to_similarity(d_u64 as f64 / 1000.0, metric) (src/index/hnsw.rs:51-75, :478-479)
@@ -330,7 +371,7 @@ __device__ __forceinline__ double hnsw_score_dev(unsigned long long d_u64)
 template <int METRIC, int S>
 __global__ __launch_bounds__(256) void k_hnsw_search(HnswGraphView g, const double* __restrict__ queries, uint32_t nq,
                                                      uint32_t ef, uint32_t entry, int max_level, uint32_t max_candidates,
-                                                     uint32_t k_stride, unsigned long long* __restrict__ out_ids,
+                                                     uint32_t refill, uint32_t k_stride, unsigned long long* __restrict__ out_ids,
                                                      double* __restrict__ out_scores, unsigned long long* __restrict__ out_n,
                                                      unsigned long long* __restrict__ stat_evals)
 {
@@ -347,8 +388,8 @@ __global__ __launch_bounds__(256) void k_hnsw_search(HnswGraphView g, const doub
     double* q = base + g.ld / 2;
     unsigned long long* t_key = reinterpret_cast<unsigned long long*>(base + q_words);  // [2][HNSW_MAX_EF]
     uint32_t* t_node = reinterpret_cast<uint32_t*>(t_key + 2 * HNSW_MAX_EF);             // [2][HNSW_MAX_EF]
-    uint32_t* stamps = g.stamps + (size_t)slot * g.cap;
-    uint32_t epoch = g.epochs[slot];
+    Visited vis;
+    vis.attach(g, slot);
 
     for (uint32_t qi = slot; qi < nq; qi += gridDim.x * 4) {
         float qq = 0.f;
@@ -364,19 +405,19 @@ __global__ __launch_bounds__(256) void k_hnsw_search(HnswGraphView g, const doub
         __builtin_amdgcn_wave_barrier();
         BeamList<S> L;
         L.init();
-        epoch += 1;
         uint32_t evals = 1;  // the entry point
         {
             unsigned long long d0 = row_distance_f32<METRIC>(g, entry, q32, q_inv, lane >> 5);
             d0 = read_lane(d0, 0);
             L.insert(d0, entry, 1);
-            if (lane == 0) stamps[entry] = epoch;
+            (void)vis.mark(entry, lane == 0);
         }
         for (int layer = max_level; layer >= 1; --layer) {
-            beam_layer_f32<METRIC, S>(g, q32, q_inv, layer, stamps, epoch, L, 1, &evals);
-            next_layer(L, stamps, epoch);
+            beam_layer_f32<METRIC, S>(g, q32, q_inv, layer, vis, L, 1, &evals);
+            next_layer(L, vis);
         }
-        beam_layer_f32<METRIC, S>(g, q32, q_inv, 0, stamps, epoch, L, (int)ef, &evals);
+        beam_layer_f32<METRIC, S>(g, q32, q_inv, 0, vis, L, (int)ef, &evals);
+        vis.clear();  // the set is empty again for this slot's next query (and for the next launch that borrows the scratch)
 
         // (1) the final beam gets the reference's own callback value: one lane walks one f64 row in index order
         //     (src/index/hnsw.rs:113-174)
@@ -415,13 +456,16 @@ __global__ __launch_bounds__(256) void k_hnsw_search(HnswGraphView g, const doub
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // (3) tombstoned nodes dropped (:475), the closest max_candidates kept (:442-448), distances -> scores
+        // (3) the closest max_candidates are what hnsw.nearest hands back (`neighbors`, :442-448); tombstoned nodes among
+        //     THEM are dropped (:475) -- fewer than k results, like the reference.  refill != 0 (a caller that named its own
+        //     ef, vl_index_search_ef): the freed slots are filled from the rest of the beam instead.  Distances -> scores
         //     (:478-479); the score never increases with the distance, so this order IS the stable sort by score (:493)
+        const uint32_t n_take = refill ? n_real : (n_real < max_candidates ? n_real : max_candidates);
         uint32_t kept = 0;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const uint32_t r = s * 64 + lane;
-            const bool in = r < n_real;
+            const bool in = r < n_take;
             const uint32_t node = in ? t_node[HNSW_MAX_EF + r] : 0u;
             const bool alive = in && g.live[node] != 0;
             const unsigned long long mk = __ballot(alive);
@@ -439,7 +483,6 @@ __global__ __launch_bounds__(256) void k_hnsw_search(HnswGraphView g, const doub
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (lane == 0) g.epochs[slot] = epoch;
 }
 
 // Build phase A: node p = first + i searches the graph of the nodes < first and fills its own lists.
@@ -458,8 +501,8 @@ __global__ __launch_bounds__(256) void k_hnsw_insert_search(HnswGraphView g, uin
     if (slot >= g.n_slots) return;
     float* q32 = reinterpret_cast<float*>(q_lds) + (size_t)wave * 2 * g.ld;
     float* cand32 = q32 + g.ld;
-    uint32_t* stamps = g.stamps + (size_t)slot * g.cap;
-    uint32_t epoch = g.epochs[slot];
+    Visited vis;
+    vis.attach(g, slot);
     uint32_t evals = 0;
 
     for (uint32_t i = slot; i < n; i += gridDim.x * 4) {
@@ -472,19 +515,40 @@ __global__ __launch_bounds__(256) void k_hnsw_insert_search(HnswGraphView g, uin
         const unsigned long long d_self = read_lane(row_distance_f32<METRIC>(g, p, q32, q_inv, half), 0);
         BeamList<S> L;
         L.init();
-        epoch += 1;
         {
             unsigned long long d0 = row_distance_f32<METRIC>(g, entry, q32, q_inv, half);
             d0 = read_lane(d0, 0);
             L.insert(d0, entry, 1);
-            if (lane == 0) stamps[entry] = epoch;
+            (void)vis.mark(entry, lane == 0);
         }
         for (int layer = max_level; layer > lp; --layer) {  // greedy descent above the node's own level
-            beam_layer_f32<METRIC, S>(g, q32, q_inv, layer, stamps, epoch, L, 1, &evals);
-            next_layer(L, stamps, epoch);
+            beam_layer_f32<METRIC, S>(g, q32, q_inv, layer, vis, L, 1, &evals);
+            next_layer(L, vis);
         }
         for (int layer = lp < max_level ? lp : max_level; layer >= 0; --layer) {
-            beam_layer_f32<METRIC, S>(g, q32, q_inv, layer, stamps, epoch, L, (int)efc, &evals);
+            beam_layer_f32<METRIC, S>(g, q32, q_inv, layer, vis, L, (int)efc, &evals);
+            if (layer == 0 && (flags & 4u)) {
+                // The walk saw the graph of the nodes < first.  The EARLIER nodes of this batch are not in it yet, so
+                // they are offered to the beam directly (their rows are complete; phase B links p into the lists of
+                // the ones it picks): node p then chooses among everything a one-by-one insertion would have shown
+                // it.  Without this a batch of rows from a region the graph does not cover yet links only to far-away
+                // old nodes, gets no incoming edge, and stays invisible to every later walk.
+                for (uint32_t base = first; base < p; base += 32) {
+                    const uint32_t e = base + (uint32_t)nl < p ? base + (uint32_t)nl : HNSW_NONE;
+                    const bool act = e != HNSW_NONE;
+                    unsigned long long de = ~0ull;
+                    if (act) de = row_distance_f32<METRIC>(g, e, q32, q_inv, half);
+                    unsigned long long w;
+                    uint32_t wn;
+                    L.get((int)efc - 1, w, wn);
+                    unsigned long long mm = __ballot(act && half == 0 && (wn == HNSW_NONE || de <= w));
+                    while (mm) {
+                        const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)mm) - 1);
+                        mm &= mm - 1;
+                        L.insert(read_lane(de, src), read_lane(e, src), (int)efc);
+                    }
+                }
+            }
             // neighbour selection (the HNSW diversity heuristic): walk the beam from the closest
             // candidate outwards and keep a candidate only if it is closer to p than to every
             // neighbour kept so far -- this is what gives the graph its long edges.  Lane j holds
@@ -573,10 +637,10 @@ __global__ __launch_bounds__(256) void k_hnsw_insert_search(HnswGraphView g, uin
                 if (layer == 0) atomicAdd(&g.indeg0[selv], 1u);  // p -> selv is an incoming edge of selv
             }
             if (lane == 0) *cnt = nsel;
-            if (layer > 0) next_layer(L, stamps, epoch);
+            if (layer > 0) next_layer(L, vis);
         }
+        vis.clear();
     }
-    if (lane == 0) g.epochs[slot] = epoch;
 }
 
 // Build phase B: add p to the lists of the neighbours it chose (replace the farthest if full and
@@ -731,8 +795,8 @@ int grid_for(const HnswGraphView& g, uint32_t work)
 }  // namespace
 
 hipError_t launch_hnsw_search(hipStream_t s, int metric, const HnswGraphView& g, const double* queries, uint32_t nq,
-                              uint32_t ef, uint32_t entry, int max_level, uint32_t max_candidates, uint32_t k_stride,
-                              unsigned long long* out_ids, double* out_scores, unsigned long long* out_n,
+                              uint32_t ef, uint32_t entry, int max_level, uint32_t max_candidates, uint32_t refill,
+                              uint32_t k_stride, unsigned long long* out_ids, double* out_scores, unsigned long long* out_n,
                               unsigned long long* stat_evals)
 {
     if (nq == 0) return hipSuccess;
@@ -747,7 +811,7 @@ hipError_t launch_hnsw_search(hipStream_t s, int metric, const HnswGraphView& g,
             const hipError_t e = allow_big_lds(kern, lds);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, g, queries, nq, ef, entry, max_level, max_candidates,
-                               k_stride, out_ids, out_scores, out_n, stat_evals);
+                               refill, k_stride, out_ids, out_scores, out_n, stat_evals);
             return hipGetLastError();
         };
         return ef <= 64 ? launch(k_hnsw_search<MM, 1>) : launch(k_hnsw_search<MM, 2>);

@@ -38,10 +38,13 @@ struct HnswGraphView {
     uint32_t* cntU;               // [slots]
     uint32_t* lock;               // [cap] link-phase spin locks
     uint32_t* indeg0;             // [cap] incoming layer-0 edges of each node: an edge is never evicted when it is the target's last
-    // visited stamps: one u32 per node per concurrently running wave
-    uint32_t* stamps;             // [n_slots, cap]
-    uint32_t* epochs;             // [n_slots]
-    uint32_t n_slots;
+    // visited sets of the walks of ONE launch (a WalkScratch the launch borrowed; hnsw_index.cpp): per walk slot a
+    // bitmap over the nodes and a log of the nodes it set; all zero between walks
+    uint32_t* vis_bits;           // [n_slots, vis_words]
+    uint32_t* vis_log;            // [n_slots, vis_log_cap]
+    uint32_t vis_words;           // ceil(cap / 32)
+    uint32_t vis_log_cap;
+    uint32_t n_slots;             // walks in flight = waves the launch may use
     uint64_t cap;
     // result post-processing on the device (query walks)
     const unsigned long long* node_id;  // [cap] node -> caller's id
@@ -50,18 +53,20 @@ struct HnswGraphView {
 
 // Query-time walk of nq queries (f64 [nq, dim]) with beam width ef, finished on the device the way
 // HNSWIndex::search finishes it on the host (src/index/hnsw.rs:468-495): the beam in (Metric::distance, node)
-// order, tombstoned nodes dropped, the closest max_candidates kept, distances converted to scores
+// order, the closest max_candidates taken and the tombstoned nodes among them dropped (refill != 0: the freed slots are
+// filled from the rest of the beam -- for callers that named their own ef), distances converted to scores
 // (convert_distance_to_similarity), ordered by score (already is: the score never increases with the distance).
 // out_ids / out_scores are [nq, k_stride], out_n is [nq]; stat_evals (optional) accumulates distance evaluations.
 hipError_t launch_hnsw_search(hipStream_t s, int metric, const HnswGraphView& g, const double* queries, uint32_t nq,
-                              uint32_t ef, uint32_t entry, int max_level, uint32_t max_candidates, uint32_t k_stride,
-                              unsigned long long* out_ids, double* out_scores, unsigned long long* out_n,
+                              uint32_t ef, uint32_t entry, int max_level, uint32_t max_candidates, uint32_t refill,
+                              uint32_t k_stride, unsigned long long* out_ids, double* out_scores, unsigned long long* out_n,
                               unsigned long long* stat_evals);
 
 // Build phase A: the rows [first, first+n) are new nodes; each walks the graph that holds the
 // nodes < first (entry/max_level describe it) with beam width ef_construction and writes its own
 // neighbour lists.  Phase B links them back into their neighbours' lists.
-// flags: bit 0 = diversity heuristic for neighbour selection, bit 1 = back-fill pruned candidates.
+// flags: bit 0 = diversity heuristic for neighbour selection, bit 1 = back-fill pruned candidates, bit 2 = offer the
+// earlier nodes of the same batch to the layer-0 beam (what a one-by-one insertion would have seen).
 hipError_t launch_hnsw_insert_search(hipStream_t s, int metric, const HnswGraphView& g, uint32_t first, uint32_t n,
                                      uint32_t ef_construction, uint32_t entry, int max_level, uint32_t flags);
 hipError_t launch_hnsw_insert_link(hipStream_t s, const HnswGraphView& g, uint32_t first, uint32_t n, int max_level);

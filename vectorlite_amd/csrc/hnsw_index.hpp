@@ -27,6 +27,23 @@ struct HnswParams {
     uint64_t seed = 0;
 };
 
+// What ONE walk launch needs besides the graph: a stream, the visited sets of its walks (per walk slot a bitmap over the
+// nodes + a log of the nodes it set, hnsw.hip: Visited) and the query / result staging buffers.  Launches borrow one from
+// a pool inside the index, so searches from different threads run their walk kernels at the same time (the reference
+// searches under RwLock::read, src/client.rs:398) -- nothing is shared between two launches but the read-only graph.
+struct WalkScratch {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t* d_bits = nullptr;   // [n_slots, words], all zero between walks
+    uint32_t* d_log = nullptr;    // [n_slots, log_cap]
+    uint32_t n_slots = 0, words = 0, log_cap = 0;
+    double* d_q = nullptr;
+    unsigned long long* d_out = nullptr;  // [nq*k ids][nq*k score bits][nq counts], one D2H copy per batch
+    unsigned long long* h_out = nullptr;  // pinned mirror
+    uint64_t q_cap = 0, out_cap = 0;
+    ~WalkScratch();
+};
+
 class HnswIndex {
 public:
     struct CoalesceReq {  // one caller waiting in search() while coalescing is on
@@ -67,15 +84,26 @@ public:
     // queries walked and Metric::distance evaluations made by them since creation (SURVEY 8(d) C4:
     // navigation evaluations read f32 rows, the final beam's exact evaluations f64 rows)
     void walk_stats(uint64_t* queries, uint64_t* distance_evals) const;
+    // beam floor of searches that name no ef (0 = the reference's strict ef = min(k, len)); at most HNSW_MAX_EF
+    void set_min_beam(uint32_t b) { min_beam_.store(b > (uint32_t)HNSW_MAX_EF ? (uint32_t)HNSW_MAX_EF : b); }
+    uint32_t min_beam() const { return min_beam_.load(); }
     int clone(HnswIndex** out) const;
     // live rows in node (insertion) order: the `vector_values` member of the serialised form
     int export_rows(uint64_t* out_ids, double* out_values) const;
+    // the graph as it stands (every node, tombstoned ones included): for inspection and CPU-side walks
+    void graph_info(uint64_t* n_nodes, uint32_t* entry, int* max_level, uint32_t* m, uint32_t* m0, uint64_t* upper_slots) const;
+    int graph_export(uint8_t* level, uint32_t* upper_off, uint32_t* cnt0, uint32_t* nbr0, uint32_t* cntU, uint32_t* nbrU,
+                     uint64_t* node_ids, uint8_t* live, double* rows) const;
 
 private:
     HnswIndex(uint64_t dim, int metric, const HnswParams& p, int device);
     int ensure_graph(uint64_t nodes, uint64_t upper_slots);
     HnswGraphView view() const;
-    int ensure_search_scratch(uint64_t nq, uint64_t k) const;
+    HnswGraphView view(const WalkScratch* ws) const;
+    WalkScratch* acquire_scratch(uint64_t walks) const;  // nullptr + last_error on failure
+    void release_scratch(WalkScratch* ws) const;
+    void drop_scratch_pool();                             // the graph's capacity changed (caller holds the unique lock)
+    int ensure_io(WalkScratch* ws, uint64_t nq, uint64_t k) const;
     int search_exact_fallback(const double* query, uint64_t k, uint64_t* out_ids, double* out_scores, uint64_t* out_n) const;
 
     const uint64_t dim_;
@@ -84,8 +112,11 @@ private:
     const int device_;
     std::unique_ptr<GpuFlatIndex> store_;
     mutable std::shared_mutex mu_;
-    mutable std::mutex search_mu_;  // walks share the per-wave visited stamps: one walk kernel at a time
-    hipStream_t stream_ = nullptr;
+    hipStream_t stream_ = nullptr;  // mutators (graph growth, level upload, tombstones)
+    mutable std::mutex pool_mu_;
+    mutable std::condition_variable pool_cv_;
+    mutable std::vector<std::unique_ptr<WalkScratch>> pool_all_;
+    mutable std::vector<WalkScratch*> pool_free_;
 
     // device graph
     uint32_t* d_nbr0_ = nullptr;
@@ -98,10 +129,7 @@ private:
     uint32_t* d_cntU_ = nullptr;
     uint32_t* d_lock_ = nullptr;
     uint32_t* d_indeg0_ = nullptr;
-    uint32_t* d_stamps_ = nullptr;
-    uint32_t* d_epochs_ = nullptr;
     uint64_t g_cap_ = 0, u_cap_ = 0;
-    uint32_t n_slots_ = 0;
 
     // host bookkeeping
     std::vector<uint8_t> level_;
@@ -115,14 +143,10 @@ private:
     std::vector<uint8_t> live_;
     uint64_t live_count_ = 0;
 
+    std::atomic<uint32_t> min_beam_{32};
     mutable std::atomic<uint64_t> stat_queries_{0}, stat_evals_{0};  // stat_evals_: the exact-fallback's share only
     mutable Coalescer<CoalesceReq> co_;
 
-    // search scratch
-    mutable double* d_q_ = nullptr;
-    mutable unsigned long long* d_out_ = nullptr;  // [nq*k ids][nq*k score bits][nq counts], one D2H copy per batch
-    mutable unsigned long long* h_out_ = nullptr;  // pinned mirror
-    mutable uint64_t q_cap_ = 0, out_cap_ = 0;
     unsigned long long* d_node_id_ = nullptr;      // [g_cap_] node -> caller's id (device copy of node_id_)
     uint8_t* d_live_ = nullptr;                    // [g_cap_] 0 = tombstoned
     unsigned long long* d_stat_evals_ = nullptr;   // distance evaluations of all query walks
