@@ -473,7 +473,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
 #define RS_NWAVES_OVERRIDE 8
 #endif
 constexpr int RS_NWAVES = RS_NWAVES_OVERRIDE;
-constexpr int RS_QPB = 128;        // queries per workgroup: 8 query blocks of 16
+// queries per workgroup: 128 (two halves of 4 query blocks) while a query row fits LDS 128 times (dims <= 384);
+// 64 at dim 768, where a row block's K is walked in two phases instead (rs_qpb(), k_mfma_rows)
+constexpr int rs_qpb(uint32_t ldb) { return ldb <= 384 ? 128 : 64; }
 constexpr int RS_SEG = 192;        // ring entries per wave
 
 
@@ -492,9 +494,19 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     constexpr int LDS_ROW = ROW_BYTES + 32;   // same padding as k_mfma_scan's row tiles: conflict-free ds_read_b128
     constexpr int KS32 = KSTEPS / 2;          // K = 32 per MFMA
     constexpr int NT = RS_NWAVES * 64;
-    constexpr int QB = RS_QPB / 16;           // 8 query blocks
-    constexpr int HQB = QB / 2;               // query blocks per half
-    constexpr int NPOS = 2 * KS32;            // (half, K-step) positions per row block
+    // A row block is worked off in NU sub-iterations that all reuse the KSP row fragments a wave holds:
+    //   dims <= 384: the whole K stays in registers (PH = 1) and the 128 queries come in QH = 2 halves of 4 query blocks;
+    //   dim 768:     K comes in PH = 2 phases of 12 K-steps (the same 96 fragment registers, refilled for the second
+    //                phase while the first runs), the accumulators live through both, 64 queries (QH = 1).
+    constexpr int PH = (KSTEPS > 24) ? 2 : 1;
+    constexpr int QH = (PH == 1) ? 2 : 1;
+    constexpr int HQB = 4;                    // query blocks (of 16) per sub-iteration
+    constexpr int QPB = QH * HQB * 16;        // queries per workgroup
+    constexpr int QB = QPB / 16;
+    constexpr int KSP = KS32 / PH;            // K-steps per phase = row fragments held per 16-row block
+    constexpr int NU = QH * PH;               // sub-iterations per row block
+    constexpr int NPOS = NU * KSP;            // (sub-iteration, K-step) positions per row block
+    static_assert(KS32 % PH == 0 && QPB == rs_qpb(LDB), "K phases are whole steps; host and kernel agree on the chunk");
     // K-steps the query fragments are read ahead of their MFMAs.  The fragment buffers rotate with the position,
     // and the rotation must close over a row block (the loop over blocks re-enters at position 0): NB | NPOS.
     constexpr int B_AHEAD = (NPOS % 3 == 0) ? 2 : 3;
@@ -503,29 +515,29 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     static_assert(KSTEPS % 2 == 0, "whole 32-deep K steps");
     constexpr int RING = (MODE == 1) ? RS_NWAVES * RS_SEG : 1;
 
-    __shared__ __attribute__((aligned(16))) unsigned char q_lds[RS_QPB * LDS_ROW];
+    __shared__ __attribute__((aligned(16))) unsigned char q_lds[QPB * LDS_ROW];
     __shared__ float ring_key[RING];
     __shared__ uint32_t ring_pos[RING];
     __shared__ unsigned short ring_q[RING];
-    __shared__ int gmax_lds[MODE == 0 ? RS_QPB : 1];
+    __shared__ int gmax_lds[MODE == 0 ? QPB : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: block numbers, row bases
                                                                 // and the partial-block branch live in scalar registers
     const int c16 = lane & 15, kg = lane >> 4;
-    const uint32_t chunk_base = blockIdx.y * RS_QPB;
+    const uint32_t chunk_base = blockIdx.y * QPB;
 
     // ---- the workgroup's queries -> LDS (the only barrier of the kernel besides MODE 0's final combine) ----
     {
         constexpr int CPR = ROW_BYTES / 16;
-        constexpr int PIECES = RS_QPB * CPR;
+        constexpr int PIECES = QPB * CPR;
         const unsigned char* src = reinterpret_cast<const unsigned char*>(q16) + (size_t)chunk_base * ROW_BYTES;
         for (int c = tid; c < PIECES; c += NT) {
             const int r = c / CPR, cc = c % CPR;
             *reinterpret_cast<u32x4*>(&q_lds[r * LDS_ROW + cc * 16]) = *reinterpret_cast<const u32x4*>(src + (size_t)c * 16);
         }
-        if (MODE == 0 && tid < RS_QPB) gmax_lds[tid] = enc_f(-INFINITY);
+        if (MODE == 0 && tid < QPB) gmax_lds[tid] = enc_f(-INFINITY);
     }
     __syncthreads();
 
@@ -555,7 +567,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     // lines; at 128 queries per workgroup the L2 request rate, not the matrix pipe, then set the pace.)
     const uint32_t lane_off = (uint32_t)lane * 16u;
     auto a_ptr = [&](uint32_t blk) { return reinterpret_cast<const unsigned char*>(slab16) + (size_t)blk * (32 * ROW_BYTES) + lane_off; };
-    bf16x8 afrag[2][KS32];
+    bf16x8 afrag[2][KSP];
     f32x4 aux[2] = {f32x4{1.f, 1.f, 1.f, 1.f}, f32x4{1.f, 1.f, 1.f, 1.f}};
     f32x4 aux2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     auto load_aux = [&](uint32_t blk) {
@@ -569,20 +581,22 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     if (has_work) {
         const unsigned char* p = a_ptr(b);
 #pragma unroll
-        for (int s = 0; s < KS32; ++s)
+        for (int s = 0; s < KSP; ++s)
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) afrag[rb][s] = *reinterpret_cast<const bf16x8*>(p + rb * (16 * ROW_BYTES) + s * 1024);
         load_aux(b);
     }
 
-    // query fragments: position i = (half, s) reads the 4 query blocks of `half` at K-step s
+    // query fragments: position i = (sub-iteration u, step s) reads 4 query blocks at one K-step --
+    // PH = 1: the blocks of half u at K-step s; PH = 2: the (only) 4 blocks at K-step u KSP + s
     const unsigned char* qrow = &q_lds[c16 * LDS_ROW + kg * 16];
     bf16x8 bq[NB][HQB];
     auto read_b = [&](int i, bf16x8(&dst)[HQB]) {
-        const int half = (i / KS32) & 1, s = i % KS32;
+        const int u = (i / KSP) % NU, s = i % KSP;
+        const int qb0 = (QH == 2) ? u * HQB : 0, kstep = (PH == 2) ? u * KSP + s : s;
 #pragma unroll
         for (int j = 0; j < HQB; ++j)
-            dst[j] = *reinterpret_cast<const bf16x8*>(qrow + (half * HQB + j) * 16 * LDS_ROW + s * 64);
+            dst[j] = *reinterpret_cast<const bf16x8*>(qrow + (qb0 + j) * 16 * LDS_ROW + kstep * 64);
     };
 #pragma unroll
     for (int i = 0; i < B_AHEAD; ++i) read_b(i, bq[i % NB]);
@@ -601,7 +615,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
             }
         }
         if (my_cnt > (uint32_t)RS_SEG) {  // the segment overflowed: candidates of any of the 128 queries may be lost -> host redoes them
-            for (uint32_t j = lane; j < (uint32_t)RS_QPB; j += 64)
+            for (uint32_t j = lane; j < (uint32_t)QPB; j += 64)
                 if (chunk_base + j < nq) atomicAdd(&cnt[chunk_base + j], cap + 1u);
         }
         my_cnt = 0;
@@ -617,6 +631,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
         const uint32_t nb_raw = b + stride;
         const uint32_t nb = nb_raw < blk_end ? nb_raw : b_last;  // the tail re-reads a valid block; its values are never used
         const unsigned char* pn = a_ptr(nb);
+        const unsigned char* pc = a_ptr(b);
         const uint32_t row0 = b * 32;
         const bool partial = row0 + 32 > n_rows;  // wave-uniform
 #if defined(RS_DBG_NOLDS) || defined(RS_DBG_NOLOAD)  // diagnostic: the fragments are opaque per block (no hoisting of the MFMAs)
@@ -625,7 +640,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
 #pragma unroll
             for (int j2 = 0; j2 < HQB; ++j2) asm volatile("" : "+v"(bq[i2][j2]));
 #pragma unroll
-        for (int s2 = 0; s2 < KS32; ++s2) {
+        for (int s2 = 0; s2 < KSP; ++s2) {
             asm volatile("" : "+v"(afrag[0][s2]));
             asm volatile("" : "+v"(afrag[1][s2]));
         }
@@ -636,16 +651,24 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
             aux_c[rb] = (METRIC != COSINE) ? aux[rb] : f32x4{1.f, 1.f, 1.f, 1.f};
             aux2_c[rb] = (METRIC == EUCLIDEAN) ? aux2[rb] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        f32x4 acc[2][HQB];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            f32x4 acc[2][HQB];
+        for (int u = 0; u < NU; ++u) {
+            const int half = (QH == 2) ? u : 0;  // which 4 query blocks this sub-iteration serves
+            if (PH == 1 || u == 0) {
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+                for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                for (int j = 0; j < HQB; ++j) acc[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int j = 0; j < HQB; ++j) acc[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            // last use of the fragments a wave holds: PH = 1 in the last half (refill for the next block); PH = 2 in
+            // BOTH phases (phase 0 refills with this block's second K half, phase 1 with the next block's first)
+            constexpr bool ALWAYS_RELOAD = PH == 2;
+            const bool reload = ALWAYS_RELOAD || u == NU - 1;
+            const unsigned char* psrc = (PH == 2 && u == 0) ? pc + (size_t)KSP * 1024 : pn;
 #pragma unroll
-            for (int s = 0; s < KS32; ++s) {
-                const int i = half * KS32 + s;
+            for (int s = 0; s < KSP; ++s) {
+                const int i = u * KSP + s;
 #ifndef RS_DBG_NOLDS
                 read_b((i + B_AHEAD) % NPOS, bq[(i + B_AHEAD) % NB]);
 #endif
@@ -663,11 +686,11 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
                     for (int rb = 0; rb < 2; ++rb)
                         acc[rb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[rb][s], bq[i % NB][j], acc[rb][j], 0, 0, 0);
 #ifndef RS_DBG_NOLOAD
-                if (half == 1) {  // last use of this K-step's row fragments: refill them for the wave's next block
+                if (reload) {  // last use of this K-step's row fragments: refill the registers
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb)
-                        afrag[rb][s] = *reinterpret_cast<const bf16x8*>(pn + rb * (16 * ROW_BYTES) + s * 1024);
-                    if (s == KS32 - 1) load_aux(nb);
+                        afrag[rb][s] = *reinterpret_cast<const bf16x8*>(psrc + rb * (16 * ROW_BYTES) + s * 1024);
+                    if (u == NU - 1 && s == KSP - 1) load_aux(nb);
                 }
 #endif
 #ifndef RS_INTERLEAVE_OFF
@@ -676,7 +699,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
                 }
-                if (half == 1) {
+                if (reload) {
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
@@ -696,7 +719,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                     for (int j = 0; j < HQB; ++j) keep += acc[rb][j][0] + acc[rb][j][1] + acc[rb][j][2] + acc[rb][j][3];
-                run_max[half] += keep;
+                run_max[u] += keep;
             }
             if (false)
 #endif
@@ -753,10 +776,12 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
                     }
                 }
             };
-            if (partial)
-                epilogue(std::true_type{});
-            else
-                epilogue(std::false_type{});
+            if (PH == 1 || u == NU - 1) {  // the sums are complete
+                if (partial)
+                    epilogue(std::true_type{});
+                else
+                    epilogue(std::false_type{});
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (MODE == 1 && my_cnt >= (uint32_t)(RS_SEG / 2)) flush_wave();  // wave-uniform
@@ -776,7 +801,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
             if (kg == 0) atomicMax(&gmax_lds[qb * 16 + c16], enc_f(mx));
         }
         __syncthreads();
-        if (tid < RS_QPB && chunk_base + tid < nq && blockIdx.x < n_groups)
+        if (tid < QPB && chunk_base + tid < nq && blockIdx.x < n_groups)
             gmax[(size_t)(chunk_base + tid) * n_groups + blockIdx.x] = gmax_lds[tid];
     }
 }
@@ -1086,7 +1111,8 @@ hipError_t launch_rows_bf16(hipStream_t s, const double* master, uint64_t n, uin
 bool mfma_rows_kernel(uint32_t dim)
 {
     const char* kv = getenv("VL_MFMA_KERNEL");
-    return mfma_ldb(dim) <= 384 && !(kv && kv[0] == 't');
+    const uint32_t ldb = mfma_ldb(dim);
+    return (ldb <= 384 || ldb == 768) && !(kv && kv[0] == 't');
 }
 
 hipError_t launch_rows_bf16_frag(hipStream_t s, const double* master_rows, uint64_t row0, uint64_t n, uint32_t dim,
@@ -1163,7 +1189,7 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     // ---- row-stationary kernel (k_mfma_rows): every dimension up to 384; VL_MFMA_KERNEL=tile keeps the LDS-tile kernel ----
     {
         if (mfma_rows_kernel(dim)) {  // slab_bf16 is then the fragment-major slab (launch_rows_bf16_frag)
-            const uint32_t rq = (uint32_t)RS_QPB;
+            const uint32_t rq = (uint32_t)rs_qpb(ldb);
             const uint32_t rnq_pad = (nq + rq - 1) / rq * rq;
             if (rnq_pad > w.nq_cap) return hipErrorInvalidValue;
             const uint32_t r_chunks = rnq_pad / rq;
@@ -1225,7 +1251,7 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
         else if (metric == EUCLIDEAN) VL_RLAUNCH2(K, EUCLIDEAN)   \
         else VL_RLAUNCH2(K, DOT)                                  \
     }
-            VL_RLAUNCH(8) VL_RLAUNCH(16) VL_RLAUNCH(24)
+            VL_RLAUNCH(8) VL_RLAUNCH(16) VL_RLAUNCH(24) VL_RLAUNCH(48)
 #undef VL_RLAUNCH
 #undef VL_RLAUNCH2
             if (!r_launched) return hipErrorInvalidValue;
