@@ -485,7 +485,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
                                                               const float* __restrict__ row_sqn,
                                                               const __bf16* __restrict__ q16, uint32_t nq,
                                                               uint32_t blk_begin, uint32_t blk_end, uint32_t n_rows,
-                                                              int* __restrict__ gmax, uint32_t n_groups,
+                                                              int* __restrict__ gmax, uint32_t n_groups, uint32_t gpw,
                                                               const float* __restrict__ thr, Cand32* __restrict__ cand,
                                                               uint32_t* __restrict__ cnt, uint32_t cap)
 {
@@ -519,7 +519,9 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     __shared__ float ring_key[RING];
     __shared__ uint32_t ring_pos[RING];
     __shared__ unsigned short ring_q[RING];
-    __shared__ int gmax_lds[MODE == 0 ? QPB : 1];
+    // MODE 0: a workgroup reports gpw groups (1, 2, 4 or 8: its waves in equal shares), so that the sampling pass can run
+    // on the same full-chip grid as pass 1 whatever the number of query chunks and still hand k_thresholds 64..256 groups
+    __shared__ int gmax_lds[MODE == 0 ? RS_NWAVES * QPB : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -537,7 +539,8 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
             const int r = c / CPR, cc = c % CPR;
             *reinterpret_cast<u32x4*>(&q_lds[r * LDS_ROW + cc * 16]) = *reinterpret_cast<const u32x4*>(src + (size_t)c * 16);
         }
-        if (MODE == 0 && tid < QPB) gmax_lds[tid] = enc_f(-INFINITY);
+        if (MODE == 0)
+            for (int c = tid; c < RS_NWAVES * QPB; c += NT) gmax_lds[c] = enc_f(-INFINITY);
     }
     __syncthreads();
 
@@ -798,11 +801,14 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
             float mx = run_max[qb];  // the four k-groups of lanes saw different rows of one query
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            if (kg == 0) atomicMax(&gmax_lds[qb * 16 + c16], enc_f(mx));
+            const uint32_t gl = (uint32_t)wave * gpw / RS_NWAVES;  // this wave's group within the workgroup
+            if (kg == 0) atomicMax(&gmax_lds[gl * QPB + qb * 16 + c16], enc_f(mx));
         }
         __syncthreads();
-        if (tid < QPB && chunk_base + tid < nq && blockIdx.x < n_groups)
-            gmax[(size_t)(chunk_base + tid) * n_groups + blockIdx.x] = gmax_lds[tid];
+        for (uint32_t c = tid; c < gpw * (uint32_t)QPB; c += NT) {
+            const uint32_t gl = c / QPB, ql = c % QPB, gidx = blockIdx.x * gpw + gl;
+            if (chunk_base + ql < nq && gidx < n_groups) gmax[(size_t)(chunk_base + ql) * n_groups + gidx] = gmax_lds[c];
+        }
     }
 }
 
@@ -1207,19 +1213,31 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
             uint32_t sample_blocks = n_blocks / sample_div;
             const uint32_t min_blocks = std::min<uint32_t>(n_blocks, 65536u / 32u);
             if (sample_blocks < min_blocks) sample_blocks = min_blocks;
-            const uint32_t r_groups = std::min<uint32_t>(sample_blocks, (uint32_t)MFMA_GROUPS);
             const uint64_t r_sample_rows = std::min<uint64_t>((uint64_t)sample_blocks * 32, n_rows);
             const uint32_t wg_cap = (uint32_t)env_grid(r_chunks);  // co-resident workgroups per query chunk
+            // sampling pass: the grid of pass 1 (every CU busy, one round), each workgroup reporting gpw groups so that
+            // k_thresholds sees up to MFMA_GROUPS of them (>= 64 as soon as the sample holds 64 blocks)
+            uint32_t gx0 = std::max<uint32_t>(1u, std::min<uint32_t>({(sample_blocks + RS_NWAVES - 1) / RS_NWAVES, wg_cap, (uint32_t)MFMA_GROUPS}));
+            uint32_t r_gpw = 1;
+            while (r_gpw < (uint32_t)RS_NWAVES && gx0 * r_gpw * 2 <= (uint32_t)MFMA_GROUPS) r_gpw *= 2;
+            if (sample_blocks < gx0 * r_gpw) {  // tiny sample: one block per group at most
+                r_gpw = RS_NWAVES;
+                gx0 = std::max<uint32_t>(1u, (sample_blocks + RS_NWAVES - 1) / RS_NWAVES);
+            }
+            const uint32_t r_groups = gx0 * r_gpw;
             uint32_t st_end[4] = {0, n_blocks, n_blocks, n_blocks};
             int r_stages = 1;
             {
                 const char* se = getenv("VL_MFMA_STAGES");
-                const int want = se && *se ? atoi(se) : 3;
+                // three stages pay for their second refine launch (~50 us with its gaps) only on long scans; a shard of
+                // ~1 M rows (config 3) is 3 % faster with two (measured: 2.015 -> 1.953 ms at 1.25 M x 768, 1024 queries)
+                const int want = se && *se ? atoi(se) : (n_blocks >= 131072u ? 3 : 2);
                 if (want >= 2 && n_blocks >= 128u * RS_NWAVES * wg_cap) {
                     r_stages = want >= 3 ? 3 : 2;
                     const char* s1 = getenv("VL_MFMA_STAGE1");
                     const char* s2 = getenv("VL_MFMA_STAGE2");
-                    const uint32_t f1 = s1 && *s1 ? (uint32_t)atoi(s1) : 3u, f2 = s2 && *s2 ? (uint32_t)atoi(s2) : 7u;  // sixteenths
+                    const uint32_t f1 = s1 && *s1 ? (uint32_t)atoi(s1) : (r_stages == 3 ? 3u : 2u);  // sixteenths
+                    const uint32_t f2 = s2 && *s2 ? (uint32_t)atoi(s2) : 7u;
                     st_end[1] = (uint32_t)((uint64_t)n_blocks * f1 / 16);
                     st_end[2] = r_stages == 3 ? (uint32_t)((uint64_t)n_blocks * f2 / 16) : n_blocks;
                     st_end[3] = n_blocks;
@@ -1228,8 +1246,8 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
             bool r_launched = false;
 #define VL_RLAUNCH2(K, MET)                                                                                                     \
     {                                                                                                                           \
-        hipLaunchKernelGGL((k_mfma_rows<K, 0, MET>), dim3(r_groups, r_chunks), dim3(RS_NWAVES * 64), 0, s, slab, row_norm,      \
-                           row_sqnorm, q16, nq, 0u, sample_blocks, (uint32_t)r_sample_rows, w.gmax, r_groups,                   \
+        hipLaunchKernelGGL((k_mfma_rows<K, 0, MET>), dim3(gx0, r_chunks), dim3(RS_NWAVES * 64), 0, s, slab, row_norm,           \
+                           row_sqnorm, q16, nq, 0u, sample_blocks, (uint32_t)r_sample_rows, w.gmax, r_groups, r_gpw,            \
                            (const float*)nullptr, (Cand32*)nullptr, (uint32_t*)nullptr, 0u);                                    \
         hipLaunchKernelGGL(k_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.gmax, r_groups, nq, q64 + (size_t)nq * dim,     \
                            w.thr);                                                                                              \
@@ -1237,7 +1255,7 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
             const uint32_t tb = st_end[st], te = st_end[st + 1];                                                                \
             const uint32_t gx = std::max<uint32_t>(1u, std::min<uint32_t>((te - tb + RS_NWAVES - 1) / RS_NWAVES, wg_cap));      \
             hipLaunchKernelGGL((k_mfma_rows<K, 1, MET>), dim3(gx, r_chunks), dim3(RS_NWAVES * 64), 0, s, slab, row_norm,        \
-                               row_sqnorm, q16, nq, tb, te, (uint32_t)n_rows, (int*)nullptr, 0u, w.thr, w.cand, w.cnt,          \
+                               row_sqnorm, q16, nq, tb, te, (uint32_t)n_rows, (int*)nullptr, 0u, 1u, w.thr, w.cand, w.cnt,      \
                                (uint32_t)MFMA_CAND_CAP);                                                                        \
             if (st + 1 < r_stages)                                                                                              \
                 hipLaunchKernelGGL(k_refine_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.cand, w.cnt,                     \
