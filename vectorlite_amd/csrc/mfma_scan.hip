@@ -731,10 +731,10 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
             // masking them costs a compare and two selects per key -- in every block, if it is written as a predicate.
             auto epilogue = [&](auto partial_tag) {
                 constexpr bool PARTIAL = decltype(partial_tag)::value;
+                float keys[HQB][8];
+                float mj[HQB];
 #pragma unroll
                 for (int j = 0; j < HQB; ++j) {
-                    const int qb = half * HQB + j;
-                    float keys[8];
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -743,37 +743,51 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
                             if (METRIC == DOT) key *= aux_c[rb][jj];                                      // x.q
                             if (METRIC == EUCLIDEAN) key = 2.0f * key * aux_c[rb][jj] - aux2_c[rb][jj];   // |q|^2 - |x - q|^2
                             if (PARTIAL && row0 + (uint32_t)(16 * rb + 4 * kg + jj) >= n_rows) key = -INFINITY;
-                            keys[4 * rb + jj] = key;
+                            keys[j][4 * rb + jj] = key;
                         }
-                    // max of the 8 keys in 4 instructions (fmaxf() costs a canonicalising v_max x, x per operand in IEEE
+                    // max of the 8 keys in 3 instructions (fmaxf() costs a canonicalising v_max x, x per operand in IEEE
                     // mode; the keys are MFMA sums of finite bf16 products)
-                    const float m = max3f(max3f(keys[0], keys[1], keys[2]), max3f(keys[3], keys[4], keys[5]), max3f(keys[6], keys[7], keys[7]));
+                    mj[j] = max3f(max3f(keys[j][0], keys[j][1], keys[j][2]), max3f(keys[j][3], keys[j][4], keys[j][5]),
+                                  max3f(keys[j][6], keys[j][7], keys[j][7]));
+                }
+                if (MODE == 0) {
+#pragma unroll
+                    for (int j = 0; j < HQB; ++j) run_max[half * HQB + j] = max3f(run_max[half * HQB + j], mj[j], mj[j]);
+                    return;
+                }
+                // ONE test and ONE branch for the 4 query blocks of the sub-iteration: does any key reach its query's
+                // threshold?  (m - T >= 0; T = +inf for padding queries gives -inf, a fully masked block gives -inf or NaN)
+                float ex[HQB];
+#pragma unroll
+                for (int j = 0; j < HQB; ++j) ex[j] = mj[j] - thr_q[half * HQB + j];
+                const float any = max3f(max3f(ex[0], ex[1], ex[2]), ex[3], ex[3]);
+                if (__builtin_amdgcn_ballot_w64(any >= 0.0f) == 0ull) return;
+                // rare; only THIS wave pays for it
+#pragma unroll
+                for (int j = 0; j < HQB; ++j) {
+                    const int qb = half * HQB + j;
                     const float tq = thr_q[qb];
-                    if (MODE == 0) {
-                        run_max[qb] = max3f(run_max[qb], m, m);
-                    } else if (__builtin_amdgcn_ballot_w64(m >= tq) != 0ull) {  // rare; only THIS wave pays for it
-                        const float m0 = fmaxf(fmaxf(keys[0], keys[1]), fmaxf(keys[2], keys[3]));
-                        const float m1 = fmaxf(fmaxf(keys[4], keys[5]), fmaxf(keys[6], keys[7]));
+                    if (__builtin_amdgcn_ballot_w64(mj[j] >= tq) == 0ull) continue;  // wave-uniform
 #pragma unroll
-                        for (int rb = 0; rb < 2; ++rb) {
-                            if (__builtin_amdgcn_ballot_w64((rb ? m1 : m0) >= tq) == 0ull) continue;  // wave-uniform
+                    for (int rb = 0; rb < 2; ++rb) {
+                        const float mrb = fmaxf(fmaxf(keys[j][4 * rb], keys[j][4 * rb + 1]), fmaxf(keys[j][4 * rb + 2], keys[j][4 * rb + 3]));
+                        if (__builtin_amdgcn_ballot_w64(mrb >= tq) == 0ull) continue;  // wave-uniform
 #pragma unroll
-                            for (int jj = 0; jj < 4; ++jj) {
-                                const float key = keys[4 * rb + jj];
-                                const bool is_cand = key >= tq && key > -INFINITY;  // masked rows are -inf; T_q may be too
-                                const unsigned long long mk = __builtin_amdgcn_ballot_w64(is_cand);
-                                if (mk != 0ull) {  // wave-uniform
-                                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32),
-                                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                                    const uint32_t slot = my_cnt + rank;
-                                    if (is_cand && slot < (uint32_t)RS_SEG) {
-                                        const uint32_t e = (uint32_t)wave * RS_SEG + slot;
-                                        ring_key[e] = key;
-                                        ring_pos[e] = row0 + (uint32_t)(16 * rb + 4 * kg + jj);
-                                        ring_q[e] = (unsigned short)(qb * 16 + c16);
-                                    }
-                                    my_cnt += (uint32_t)__popcll(mk);
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const float key = keys[j][4 * rb + jj];
+                            const bool is_cand = key >= tq && key > -INFINITY;  // masked rows are -inf; T_q may be too
+                            const unsigned long long mk = __builtin_amdgcn_ballot_w64(is_cand);
+                            if (mk != 0ull) {  // wave-uniform
+                                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32),
+                                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                                const uint32_t slot = my_cnt + rank;
+                                if (is_cand && slot < (uint32_t)RS_SEG) {
+                                    const uint32_t e = (uint32_t)wave * RS_SEG + slot;
+                                    ring_key[e] = key;
+                                    ring_pos[e] = row0 + (uint32_t)(16 * rb + 4 * kg + jj);
+                                    ring_q[e] = (unsigned short)(qb * 16 + c16);
                                 }
+                                my_cnt += (uint32_t)__popcll(mk);
                             }
                         }
                     }
@@ -1209,7 +1223,9 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
             const uint32_t n_blocks = (uint32_t)((n_rows + 31) / 32);
             // pass 0 over a sample of the blocks (>= 65536 rows or everything): one group per workgroup
             const char* sd = getenv("VL_MFMA_SAMPLE_DIV");
-            const uint32_t sample_div = sd && *sd && atoi(sd) > 0 ? (uint32_t)atoi(sd) : 32u;
+            // 1/32 of the blocks; 1/64 on long scans (>= 4 M rows), where the floor of 65536 rows is far away and the
+            // looser thresholds only add a few hundred candidates per query to the first stage
+            const uint32_t sample_div = sd && *sd && atoi(sd) > 0 ? (uint32_t)atoi(sd) : (n_blocks >= 131072u ? 64u : 32u);
             uint32_t sample_blocks = n_blocks / sample_div;
             const uint32_t min_blocks = std::min<uint32_t>(n_blocks, 65536u / 32u);
             if (sample_blocks < min_blocks) sample_blocks = min_blocks;
