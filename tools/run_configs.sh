@@ -8,5 +8,5 @@ echo "== headline: flat cosine N=10M d384 k10, single query (bench.py)";        
 echo "== config 2: flat cosine N=1M d384 k10, single query";                        python bench.py --rows 1000000 --no-cpu-baseline --no-checks | cut -c1-400
 echo "== config 3 (one rank's shard): flat L2 1.25M x 768, batch 1024";             python tools/bench_sharded.py --rows 1250000 --dim 768 --batch 1024 --steps 10
 echo "== config 4: HNSW cosine N=1M d384, ef 10 (reference) .. 128";                python tools/hnsw_eval.py --rows 1000000 --dim 384 --latent 16 --nq 2000 | tail -5
-echo "== config 5: batched flat Q=4096 N=10M d384 (bf16 MFMA filter + exact finalize)"; python tools/bench_batch.py --nq 4096 | tail -3
+echo "== config 5: batched flat Q=4096 N=10M d384 (bf16 MFMA filter + exact finalize)"; python tools/bench_mfma.py --config c5 | cut -c1-700
 echo "== concurrent callers, coalesced";                                            python tools/bench_coalesce.py | tail -3
