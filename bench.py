@@ -40,6 +40,7 @@ import socket
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 import numpy as np
@@ -423,8 +424,66 @@ def run_rank(args) -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t.item())
 
+    def sharded_check():
+        """Every rank, after the timed region (N > 1 only; informational, never part of `value`): the row-sharded
+        batched search of config 3's kind on small shards -- each rank scans its own rows, ONE ncclAllGather inside
+        libvectorlite_amd.so (vl_shard_search_batch), device merge -- and the ranks compare digests of the answer."""
+        from vectorlite_amd.sharded import Comm, ShardedFlatIndex
+        rows_per, nqs = 200_000, 256
+        shard = V.FlatIndex(dim, device=dev_index)
+        g = torch.Generator(device=dev)
+        g.manual_seed(777 + rank)
+        x = torch.randn((rows_per, dim), dtype=torch.float64, device=dev, generator=g)
+        x /= torch.linalg.vector_norm(x, dim=1, keepdim=True)
+        shard.add_rows(ids_for(rank * rows_per, rows_per), x, validate=False)
+        del x
+        Qs = unit_queries(2468, nqs, dim)  # the same batch on every rank
+        comm = None
+        if rehearse:  # ranks share one card and RCCL refuses that: the records travel by gloo, the merge is the same kernel
+            sh = ShardedFlatIndex(shard, transport="torch")
+        else:
+            comm = Comm.from_torch_distributed(device=dev_index)
+            sh = ShardedFlatIndex(shard, comm=comm)
+        assert (sh.offset, sh.total) == (rank * rows_per, world * rows_per)
+        sh.search_batch(Qs, k, metric)
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(3):
+            si, ss, sn, sp = sh.search_batch(Qs, k, metric, with_positions=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - ts) / 3
+        dig = torch.tensor([int(np.bitwise_xor.reduce(np.ascontiguousarray(si).reshape(-1).view(np.int64))),
+                            int(np.bitwise_xor.reduce(np.ascontiguousarray(ss).reshape(-1).view(np.int64)))],
+                           dtype=torch.int64, device="cpu" if rehearse else dev)
+        lo, hi = dig.clone(), dig.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        same = bool((lo == hi).all().item())
+        own_ok = 0
+        for qi in range(4):  # this rank's rows in the global answer are what its own single search() returns for them
+            li, ls = shard.search_arrays(Qs[qi], k, metric)
+            mine = [(int(i), float(sc)) for i, sc, pp in zip(si[qi], ss[qi], sp[qi]) if rank * rows_per <= int(pp) < (rank + 1) * rows_per]
+            own_ok += int(mine == list(zip(li.tolist(), ls.tolist()))[: len(mine)])
+        tm = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        if comm is not None:
+            comm.close()
+        return {"transport": "gloo records + device merge (rehearsal on one card)" if rehearse else "RCCL: one ncclAllGather per batch inside the library (vl_shard_search_batch)",
+                "shards": world, "rows_per_shard": rows_per, "queries": nqs, "ms_per_batch": round(float(tm.item()) * 1e3, 3),
+                "identical_on_every_rank": same, "own_rows_match_single_search": f"{own_ok}/4"}
+
+    run_sharded = use_dist and world > 1 and not args.no_checks
     if rank != 0:
         dist.barrier()  # rank 0 has published the line
+        if run_sharded:
+            wd = threading.Timer(180.0, lambda: os._exit(0))  # never outlive a stuck collective
+            wd.daemon = True
+            wd.start()
+            try:
+                sharded_check()
+            except BaseException as e:  # noqa: BLE001
+                log(f"[bench] rank {rank}: row-sharded check failed: {type(e).__name__}: {e}")
+            wd.cancel()
         dist.destroy_process_group()
         return 0
 
@@ -509,6 +568,19 @@ def run_rank(args) -> int:
         dist.barrier()
 
     extras = world == 1 and not args.no_checks  # N>1: every rank leaves together, nothing runs on rank 0 alone
+
+    if run_sharded:
+        def on_stuck():  # a collective that never returns must not take the measured line with it
+            errors.append({"block": "row_sharded_check", "error": "no answer within 180 s: abandoned"})
+            publish()
+            if not args.result_file:
+                os.write(real_stdout, (json.dumps(out) + "\n").encode())
+            os._exit(0)
+        wd = threading.Timer(180.0, on_stuck)
+        wd.daemon = True
+        wd.start()
+        block("row_sharded_check", lambda: out["config"].__setitem__("row_sharded_check", sharded_check()))
+        wd.cancel()
 
     # ---- CPU baseline: the oracle (reference-faithful restatement), bounded sample ---------------
     def cpu_block():

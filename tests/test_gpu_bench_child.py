@@ -68,3 +68,7 @@ def test_bench_two_ranks_without_an_external_launcher():
     assert "replicas" in out["config"]["parallelism"]
     assert out["value"] > 0 and out["roofline"]["launches_timed"] == 4
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
+    # after the timed region the ranks also answer one row-sharded batch together (device merge; RCCL on real multi-GPU)
+    rs = out["config"]["row_sharded_check"]
+    assert rs["shards"] == 2 and rs["identical_on_every_rank"] is True and rs["own_rows_match_single_search"] == "4/4"
+    assert "errors" not in out, out.get("errors")
