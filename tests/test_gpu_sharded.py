@@ -178,3 +178,28 @@ def test_config3_shard_shape_through_vl_shard_search_batch():
         assert n3.tolist() == [0, 0]
     finally:
         comm.close()
+
+
+def test_a_nan_score_on_one_shard_is_the_whole_calls_panic():
+    """FlatIndex::search panics on a NaN score (partial_cmp().unwrap(), src/index/flat.rs:116) -> VL_ERR_NAN_SCORE; in the
+    sharded form the failing shard's status travels inside the exchange and every rank reports it."""
+    import vectorlite_amd as V
+    from vectorlite_amd.sharded import Comm, ShardedFlatIndex
+    rng = np.random.default_rng(2)
+    rows = rng.standard_normal((500, 8))
+    rows[77, 3] = np.inf                      # inf - inf in the Euclidean difference of a query with +inf there
+    shard = V.FlatIndex(8, device=0)
+    shard.add_rows(np.arange(500, dtype=np.uint64), rows, validate=False)
+    q = rng.standard_normal((3, 8))
+    q[1, 3] = np.inf
+    comm = Comm(Comm.unique_id(), 1, 0, 0)
+    try:
+        sh = ShardedFlatIndex(shard, comm=comm)
+        with pytest.raises(V.NaNScore):
+            sh.search_batch(q, 5, V.SimilarityMetric.Euclidean)
+        with pytest.raises(V.NaNScore):   # the plain batch entry says the same
+            shard.search_batch(q, 5, V.SimilarityMetric.Euclidean)
+        ids, scores, n = sh.search_batch(q[[0, 2]], 5, V.SimilarityMetric.Euclidean)   # the other queries are fine
+        assert n.tolist() == [5, 5]
+    finally:
+        comm.close()
