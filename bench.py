@@ -476,7 +476,7 @@ def run_rank(args) -> int:
     if rank != 0:
         dist.barrier()  # rank 0 has published the line
         if run_sharded:
-            wd = threading.Timer(180.0, lambda: os._exit(0))  # never outlive a stuck collective
+            wd = threading.Timer(120.0, lambda: os._exit(0))  # never outlive a stuck collective
             wd.daemon = True
             wd.start()
             try:
@@ -571,12 +571,12 @@ def run_rank(args) -> int:
 
     if run_sharded:
         def on_stuck():  # a collective that never returns must not take the measured line with it
-            errors.append({"block": "row_sharded_check", "error": "no answer within 180 s: abandoned"})
+            errors.append({"block": "row_sharded_check", "error": "no answer within 120 s: abandoned"})
             publish()
             if not args.result_file:
                 os.write(real_stdout, (json.dumps(out) + "\n").encode())
             os._exit(0)
-        wd = threading.Timer(180.0, on_stuck)
+        wd = threading.Timer(120.0, on_stuck)
         wd.daemon = True
         wd.start()
         block("row_sharded_check", lambda: out["config"].__setitem__("row_sharded_check", sharded_check()))
