@@ -992,3 +992,42 @@ def test_embedding_ingest_chunks_duplicates_and_hnsw(V, O):
     with pytest.raises(V.IndexOpError, match="already exists"):
         h.add_embeddings([1000, 17], eh[:2])
     assert len(h) == 301
+
+
+def test_coalesced_searches_with_a_huge_k_do_not_wedge_the_queue(V, O):
+    """a coalesced pass sized its scratch with the caller's raw k -- k = 2^64 - 1 threw length_error with the
+    leader flag set and every later coalesced search blocked forever; k = 2^63 with two queries wrapped the size to 0.
+    Every caller must get min(k, len) results, and the queue must keep working afterwards."""
+    import threading
+    rng = np.random.default_rng(404)
+    n, dim = 9000, 16
+    rows = unit_rows(rng, n, dim)
+    ids = permuted_ids(n)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    Q = unit_rows(rng, 8, dim)
+    want = [ref.search(Q[i], n, 0) for i in range(8)]
+    gpu.set_coalescing(16, 5000)  # a 5 ms window: the threads below really share passes
+    out, errors = {}, []
+    bar = threading.Barrier(8)
+
+    def worker(t, k):
+        try:
+            bar.wait()
+            out[t] = gpu.search_arrays(Q[t], k, 0)
+        except Exception as e:  # pragma: no cover
+            errors.append((t, repr(e)))
+
+    for k in (2 ** 64 - 1, 2 ** 63, n + 5):
+        out.clear()
+        th = [threading.Thread(target=worker, args=(t, k)) for t in range(8)]
+        [x.start() for x in th]
+        [x.join(timeout=120) for x in th]
+        assert not any(x.is_alive() for x in th), "a coalesced search never returned"
+        assert errors == []
+        for t in range(8):
+            gi, gs = out[t]
+            assert gi.tolist() == want[t][0].tolist() and gs.tolist() == want[t][1].tolist(), (k, t)
+    gi, gs = gpu.search_arrays(Q[0], 10, 0)  # and an ordinary search afterwards
+    assert gi.tolist() == want[0][0][:10].tolist()

@@ -389,3 +389,28 @@ def test_no_node_is_orphaned_in_a_tiny_dense_index(V):
         idx.add_rows(np.arange(40, dtype=np.uint64), rows)
         bi, bs, bn = idx.search_batch(rows[:6] + 0.05, 128, V.SimilarityMetric.Euclidean)
         assert bn.tolist() == [40] * 6, (seed, bn.tolist())
+
+
+def test_huge_k_on_a_small_hnsw_index_returns_len_results(V):
+    """k is the caller's; scratch and the kernel's output stride are sized by the beam (k near 2^63 used
+    to wrap nq * (2k + 1) and let the walk write past a few-byte buffer; a large k on a small index was an OOM)."""
+    rng = np.random.default_rng(12)
+    n, dim = 37, 6
+    rows = rng.standard_normal((n, dim))
+    idx = V.HNSWIndex(dim, V.SimilarityMetric.Euclidean)
+    idx.add_rows(np.arange(n, dtype=np.uint64) + 100, rows)
+    want = [r.id for r in idx.search(rows[3], n, V.SimilarityMetric.Euclidean)]
+    assert len(want) == n and want[0] == 103
+    L = idx._L
+    import ctypes as C
+    q = np.ascontiguousarray(rows[3])
+    for k in (10 ** 6, 2 ** 40, 2 ** 63, 2 ** 64 - 1):
+        ids = np.zeros(n, np.uint64)          # min(k, len) entries: what the header asks a caller to provide
+        scores = np.zeros(n, np.float64)
+        cnt = C.c_uint64(0)
+        rc = L.vl_index_search(idx._h, q.ctypes.data_as(C.POINTER(C.c_double)), dim, k, int(V.SimilarityMetric.Euclidean),
+                               ids.ctypes.data_as(C.POINTER(C.c_uint64)), scores.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt))
+        assert rc == 0 and cnt.value == n, (k, rc, cnt.value)
+        assert ids.tolist() == want
+    # the Python wrapper clamps k to its buffers the same way
+    assert [r.id for r in idx.search(rows[3], 2 ** 62, V.SimilarityMetric.Euclidean)] == want

@@ -291,13 +291,14 @@ class FlatIndex:
         if Q.ndim != 2:
             raise ValueError("queries must be [nq, dim]")
         nq, qlen = Q.shape
-        kk = max(int(k), 1)
+        kk = max(min(int(k), self.len()), 1)   # min(k, len) results at most; k is clamped to the buffers
+        kc = min(int(k), kk)
         ids = np.zeros((nq, kk), dtype=np.uint64)
         scores = np.zeros((nq, kk), dtype=np.float64)
         n = np.zeros(max(nq, 1), dtype=np.uint64)
-        _raise(self._L.vl_index_search_batch(self._h, _pf64(Q), nq, qlen, int(k), int(metric), _pu64(ids),
+        _raise(self._L.vl_index_search_batch(self._h, _pf64(Q), nq, qlen, kc, int(metric), _pu64(ids),
                                              _pf64(scores), _pu64(n)))
-        return ids[:, : int(k)], scores[:, : int(k)], n[:nq]
+        return ids[:, :kc], scores[:, :kc], n[:nq]
 
     def search_batch_positions(self, queries, k: int, metric: int = 0):
         """(positions, ids, scores, n), each [nq, k] ([nq] for n): the batched search_positions."""
@@ -305,14 +306,15 @@ class FlatIndex:
         if Q.ndim != 2:
             raise ValueError("queries must be [nq, dim]")
         nq, qlen = Q.shape
-        kk = max(int(k), 1)
+        kk = max(min(int(k), self.len()), 1)
+        kc = min(int(k), kk)
         pos = np.zeros((nq, kk), dtype=np.uint64)
         ids = np.zeros((nq, kk), dtype=np.uint64)
         scores = np.zeros((nq, kk), dtype=np.float64)
         n = np.zeros(max(nq, 1), dtype=np.uint64)
-        _raise(self._L.vl_index_search_batch_positions(self._h, _pf64(Q), nq, qlen, int(k), int(metric), _pu64(pos),
+        _raise(self._L.vl_index_search_batch_positions(self._h, _pf64(Q), nq, qlen, kc, int(metric), _pu64(pos),
                                                        _pu64(ids), _pf64(scores), _pu64(n)))
-        return pos[:, : int(k)], ids[:, : int(k)], scores[:, : int(k)], n[:nq]
+        return pos[:, :kc], ids[:, :kc], scores[:, :kc], n[:nq]
 
     def add_rows(self, ids, values, validate: bool = True) -> None:
         """n x add() in one device pass.  `values`: [n, dim] f64 numpy array, or a torch CUDA/HIP
@@ -553,14 +555,17 @@ class HNSWIndex:
         if Q.ndim == 1:
             Q = Q[None, :]
         nq, qlen = Q.shape
-        kk = max(int(k), 1)
+        # buffers hold min(k, len) entries per query and k is clamped to them (a prefix of the same ranking): a huge k
+        # costs nothing, and an add() from another thread after len() was read cannot make the library overrun them
+        kk = max(min(int(k), self.len()), 1)
+        kc = min(int(k), kk)
         ids = np.zeros((nq, kk), dtype=np.uint64)
         scores = np.zeros((nq, kk), dtype=np.float64)
         n = np.zeros(max(nq, 1), dtype=np.uint64)
-        rc = self._L.vl_index_search_ef(self._h, _pf64(Q), nq, qlen, int(k), int(ef), int(metric), _pu64(ids),
+        rc = self._L.vl_index_search_ef(self._h, _pf64(Q), nq, qlen, kc, int(ef), int(metric), _pu64(ids),
                                         _pf64(scores), _pu64(n))
         self._raise_search(rc, metric)
-        return ids[:, : int(k)], scores[:, : int(k)], n[:nq]
+        return ids[:, :kc], scores[:, :kc], n[:nq]
 
     def search_arrays(self, query, k: int, metric: int, ef: int = 0):
         ids, scores, n = self.search_batch(_f64(query).ravel()[None, :], k, metric, ef)
@@ -569,11 +574,11 @@ class HNSWIndex:
 
     def search(self, query, k: int, similarity_metric: int) -> List[SearchResult]:
         q = _f64(query).ravel()
-        kk = max(int(k), 1)
+        kk = max(min(int(k), self.len()), 1)
         ids = np.zeros(kk, dtype=np.uint64)
         scores = np.zeros(kk, dtype=np.float64)
         n = C.c_uint64(0)
-        rc = self._L.vl_index_search(self._h, _pf64(q), q.size, int(k), int(similarity_metric), _pu64(ids),
+        rc = self._L.vl_index_search(self._h, _pf64(q), q.size, min(int(k), kk), int(similarity_metric), _pu64(ids),
                                      _pf64(scores), C.byref(n))
         self._raise_search(rc, similarity_metric)
         out = []
