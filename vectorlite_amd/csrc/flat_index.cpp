@@ -1078,12 +1078,19 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, uint64
     // (2 + u) * u with u = 2^-8 + 2^-23 (f64 -> f32 -> bf16 double rounding), see DESIGN.md
     const double in_extra = 0.0079;
     const bool prof = profile_.load();
+    static const bool trace = getenv("VL_TRACE_BATCH") != nullptr;  // diagnostic: host-side phases of a sequence on stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count();
+    };
     for (uint64_t q0 = 0; q0 < nq; q0 += MFMA_MAX_BATCH) {
+        const auto t_0 = now();
         const uint32_t g = (uint32_t)std::min<uint64_t>(MFMA_MAX_BATCH, nq - q0);
         double* norms = ws->mf_h_q64 + (size_t)g * dim_;
         std::vector<uint8_t> in_domain(g);
         for (uint32_t j = 0; j < g; ++j)
             in_domain[j] = stage_query(queries + (q0 + j) * dim_, ws->mf_h_q64 + (size_t)j * dim_, dim_, &norms[j]) ? 1 : 0;
+        const auto t_1 = now();
         VL_HIP(hipMemcpyAsync(ws->mf_d_q64, ws->mf_h_q64, ((size_t)g * dim_ + g) * sizeof(double), hipMemcpyHostToDevice, st));
         if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
         VL_HIP(launch_mfma_candidates(st, metric, slab16, d_norm16_, d_sqnorm_, ws->mf_d_q64, g, n, (uint32_t)dim_,
@@ -1092,7 +1099,9 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, uint64
         VL_HIP(launch_merge_finalize(st, metric, ws->mf_lists, 1, (int)g, d_master_, ws->mf_d_q64,
                                      ws->mf_d_q64 + (size_t)g * dim_, (uint32_t)dim_, n, (uint32_t)k_eff, max_row_norm_,
                                      ws->mf_h_result, in_extra));
+        const auto t_2 = now();
         VL_HIP(hipStreamSynchronize(st));
+        const auto t_3 = now();
         if (prof) {
             float ms = 0.f;
             VL_HIP(hipEventElapsedTime(&ms, ws->ev0, ws->ev1));
@@ -1101,6 +1110,20 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, uint64
             prof_ms_ += ms;
             prof_bytes_ += n * (uint64_t)mfma_ldb((uint32_t)dim_) * 2;
         }
+        struct TraceOut {
+            bool on;
+            std::chrono::steady_clock::time_point t0, t1, t2, t3;
+            uint32_t g;
+            ~TraceOut()
+            {
+                if (!on) return;
+                const auto t4 = std::chrono::steady_clock::now();
+                auto d = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+                fprintf(stderr, "[vl batch] %u queries: stage %ld us, enqueue %ld us, wait %ld us, unpack %ld us\n", g, d(t0, t1),
+                        d(t1, t2), d(t2, t3), d(t3, t4));
+            }
+        } trace_out{trace, t_0, t_1, t_2, t_3, g};
+        (void)us;
         for (uint32_t j = 0; j < g; ++j) {
             const uint64_t qi = q0 + j;
             const SearchResultBlock& r = ws->mf_h_result[j];
