@@ -44,6 +44,26 @@ __device__ __forceinline__ int enc_f(float f)
 }
 __device__ __forceinline__ float dec_f(int e) { return __int_as_float(e >= 0 ? e : e ^ 0x7FFFFFFF); }
 
+// The 64th largest of the 64 * VALS values a wave holds (VALS per lane; pad with -inf): a bit-by-bit search on the
+// order-preserving encoding, 32 rounds of VALS ballots -- no insertion loop, no dependence on the order of the input.
+// Fewer than 64 finite values give -inf (the padding is then the 64th largest).
+template <int VALS>
+__device__ __forceinline__ float kth64_of_wave(const float (&v)[VALS])
+{
+    uint32_t u[VALS];
+#pragma unroll
+    for (int i = 0; i < VALS; ++i) u[i] = (uint32_t)enc_f(v[i]) ^ 0x80000000u;  // unsigned order = float order
+    uint32_t t = 0;
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t c = t | (1u << b);
+        uint32_t n_ge = 0;
+#pragma unroll
+        for (int i = 0; i < VALS; ++i) n_ge += (uint32_t)__popcll(__ballot(u[i] >= c));
+        if (n_ge >= 64u) t = c;  // wave-uniform
+    }
+    return dec_f((int)(t ^ 0x80000000u));
+}
+
 // max of three finite floats in one instruction (fmaxf() costs a canonicalising v_max x, x per operand in IEEE mode;
 // the operands here are MFMA sums of finite bf16 products, or -inf)
 __device__ __forceinline__ float max3f(float a, float b, float c)
@@ -922,50 +942,97 @@ __global__ __launch_bounds__(256) void k_thresholds(const int* __restrict__ gmax
     const int lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
-    TopList<float> L;
-    L.init();
-    for (uint32_t g0 = 0; g0 < n_groups; g0 += 64) {
-        const uint32_t g = g0 + lane;
-        const bool ok = g < n_groups;
-        const float v = ok ? dec_f(gmax[(size_t)q * n_groups + g]) : -INFINITY;
-        L.offer(v, g, ok && v > -INFINITY);
+    constexpr int VALS = MFMA_GROUPS / 64;  // all loads first, then one selection: no load -> insert -> load chain
+    float v[VALS];
+#pragma unroll
+    for (int i = 0; i < VALS; ++i) {
+        const uint32_t g = (uint32_t)(lane + 64 * i);
+        v[i] = g < n_groups ? dec_f(gmax[(size_t)q * n_groups + g]) : -INFINITY;
     }
-    // lane 63 holds the 64th largest (or the sentinel when there are fewer than 64 finite maxima)
-    const float t = read_lane(L.key, 63);
-    const uint32_t p = read_lane(L.pos, 63);
-    if (lane == 0) thr[q] = (q_norms[q] == 0.0) ? INFINITY : ((p == POS_SENTINEL) ? -INFINITY : t);
+    const float t = kth64_of_wave<VALS>(v);  // -inf when fewer than 64 groups hold rows
+    if (lane == 0) thr[q] = (q_norms[q] == 0.0) ? INFINITY : t;
 }
 
-// Per query: top-64 of its candidate buffer by (key desc, position asc) -> one sorted list.
+// Per query: top-64 of its candidate buffer by (key desc, position asc) -> one sorted list.  One wave per query.
+// Up to 1024 candidates (the usual few hundred) sit in registers as 64-bit composites (order-preserving key bits,
+// then ~position): a bit-by-bit search finds the 64th largest composite, the <= 64 entries at or above it are
+// compacted through LDS and ranked by counting -- no insertion loop over the whole buffer.  Longer buffers (up to the
+// cap) take the sorted-list path.
 __global__ __launch_bounds__(256) void k_select_candidates(const Cand32* __restrict__ cand,
-                                                           const uint32_t* __restrict__ cnt, uint32_t cap,
+                                                           const uint32_t* __restrict__ cnt, uint32_t cap, uint32_t nq,
                                                            Cand32* __restrict__ lists)
 {
-    __shared__ Cand32 sh[4 * 64];
+    __shared__ unsigned long long sh[4][64];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const uint32_t q = blockIdx.x;
+    const uint32_t q = blockIdx.x * 4 + wave;
+    if (q >= nq) return;
     const uint32_t n = cnt[q];
+    const Cand32* mine = cand + (size_t)q * cap;
+    Cand32* out = lists + (size_t)q * KP;
+    Cand32 res;
+    res.key = -INFINITY;
+    res.pos = POS_SENTINEL;
+    if (n > cap) {  // an overflowed buffer yields an all-sentinel list: the host redoes that query
+        out[lane] = res;
+        return;
+    }
+    if (n <= 1024u) {
+        constexpr int VALS = 16;
+        unsigned long long c[VALS];
+#pragma unroll
+        for (int i = 0; i < VALS; ++i) {
+            const uint32_t jx = (uint32_t)(lane + 64 * i);
+            c[i] = 0ull;  // below every real composite (a real one has ~pos >= 1 in its low word: pos < 0xFFFFFFFF)
+            if (jx < n) {
+                const Cand32 e = mine[jx];
+                c[i] = ((unsigned long long)((uint32_t)enc_f(e.key) ^ 0x80000000u) << 32) | (unsigned long long)(0xFFFFFFFFu - e.pos);
+            }
+        }
+        unsigned long long t = 0ull;  // the 64th largest composite (0 when there are fewer than 64)
+        for (int b = 63; b >= 0; --b) {
+            const unsigned long long tc = t | (1ull << b);
+            uint32_t n_ge = 0;
+#pragma unroll
+            for (int i = 0; i < VALS; ++i) n_ge += (uint32_t)__popcll(__ballot(c[i] >= tc));
+            if (n_ge >= 64u) t = tc;  // wave-uniform
+        }
+        uint32_t base = 0;
+#pragma unroll
+        for (int i = 0; i < VALS; ++i) {
+            const bool sel = c[i] != 0ull && c[i] >= t;
+            const unsigned long long mk = __ballot(sel);
+            const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            if (sel && slot < 64u) sh[wave][slot] = c[i];
+            base += (uint32_t)__popcll(mk);
+        }
+        const uint32_t kept = base < 64u ? base : 64u;  // composites are distinct (positions are), so base <= 64
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long me = (uint32_t)lane < kept ? sh[wave][lane] : 0ull;
+        uint32_t rank = 0;
+        for (int jx = 0; jx < 64; ++jx) rank += read_lane(me, jx) > me ? 1u : 0u;
+        if ((uint32_t)lane < kept) {
+            res.key = dec_f((int)((uint32_t)(me >> 32) ^ 0x80000000u));
+            res.pos = 0xFFFFFFFFu - (uint32_t)me;
+            out[rank] = res;
+        } else {
+            out[lane] = res;  // sentinels behind the real entries
+        }
+        return;
+    }
     TopList<float> L;
     L.init();
-    if (n <= cap) {  // an overflowed buffer yields an all-sentinel list: the host redoes that query
-        for (uint32_t i0 = wave * 64; i0 < n; i0 += 256) {
-            const uint32_t i = i0 + lane;
-            const bool ok = i < n;
-            Cand32 e;
-            e.key = 0.f;
-            e.pos = 0;
-            if (ok) e = cand[(size_t)q * cap + i];
-            L.offer(e.key, e.pos, ok);
-        }
-    }
-    block_merge<float, Cand32, 4>(L, sh);
-    if (wave == 0) {
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t jx = i0 + lane;
         Cand32 e;
-        e.key = L.key;
-        e.pos = L.pos;
-        lists[(size_t)q * KP + lane] = e;
+        e.key = 0.f;
+        e.pos = 0;
+        if (jx < n) e = mine[jx];
+        L.offer(e.key, e.pos, jx < n);
     }
+    res.key = L.key;
+    res.pos = L.pos;
+    out[lane] = res;
 }
 
 // Between two stages of pass 1: T_q = max(T_q, 64th largest key among the candidates found so far).
@@ -980,6 +1047,17 @@ __global__ __launch_bounds__(256) void k_refine_thresholds(const Cand32* __restr
     if (q >= nq) return;
     const uint32_t n = cnt[q];
     if (n < 64u || n > cap) return;  // too few to say anything / overflowed (the host redoes that query)
+    if (n <= 512u) {  // the usual case between stages: every candidate key in registers, one selection
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t j = (uint32_t)(lane + 64 * i);
+            v[i] = j < n ? cand[(size_t)q * cap + j].key : -INFINITY;
+        }
+        const float t64 = kth64_of_wave<8>(v);
+        if (lane == 0 && t64 > thr[q]) thr[q] = t64;
+        return;
+    }
     TopList<float> L;
     L.init();
     for (uint32_t i0 = 0; i0 < n; i0 += 64) {
@@ -1289,7 +1367,7 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
 #undef VL_RLAUNCH
 #undef VL_RLAUNCH2
             if (!r_launched) return hipErrorInvalidValue;
-            hipLaunchKernelGGL(k_select_candidates, dim3(nq), dim3(256), 0, s, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, out_lists);
+            hipLaunchKernelGGL(k_select_candidates, dim3((nq + 3) / 4), dim3(256), 0, s, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, nq, out_lists);
             return hipGetLastError();
         }
     }
@@ -1335,7 +1413,7 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
 #undef VL_LAUNCH2
 #undef VL_LAUNCH3
     if (!launched) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_select_candidates, dim3(nq), dim3(256), 0, s, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, out_lists);
+    hipLaunchKernelGGL(k_select_candidates, dim3((nq + 3) / 4), dim3(256), 0, s, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, nq, out_lists);
     return hipGetLastError();
 }
 
