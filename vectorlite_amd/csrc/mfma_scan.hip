@@ -744,7 +744,6 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
                     for (int j = 0; j < HQB; ++j) keep += acc[rb][j][0] + acc[rb][j][1] + acc[rb][j][2] + acc[rb][j][3];
                 run_max[u] += keep;
             }
-            if (false)
 #endif
             // ---- epilogue of this half: C layout of a 16x16 block: column = lane & 15 (query), row = 4 (lane >> 4) + reg ----
             // Two copies selected by ONE wave-uniform branch: only the index's last block can hold rows past n_rows, and
@@ -813,12 +812,16 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
                     }
                 }
             };
+#ifndef RS_DBG_NOEPI
             if (PH == 1 || u == NU - 1) {  // the sums are complete
                 if (partial)
                     epilogue(std::true_type{});
                 else
                     epilogue(std::false_type{});
             }
+#else
+            (void)epilogue;
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         if (MODE == 1 && my_cnt >= (uint32_t)(RS_SEG / 2)) flush_wave();  // wave-uniform
