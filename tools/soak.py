@@ -43,7 +43,21 @@ while time.time() < t_end:
         h.add_rows(np.arange(n, dtype=np.uint64), rows)
         r = h.search(Q[3], 10, 0); searches += 1
         assert len(r) == 10
+        # concurrent walks, each borrowing its own scratch from the pool, while a batch runs too
+        hw = [h.search_arrays(Q[j], 10, 0, ef=48) for j in range(8)]
+        ht = [threading.Thread(target=lambda t=t: [h.search_arrays(Q[(t + j) % 8], 10, 0, ef=48) for j in range(6)]) for t in range(8)]
+        [x.start() for x in ht]; hb = h.search_batch(Q[:8], 10, 0, ef=48); [x.join() for x in ht]; searches += 56
+        assert all(hb[0][j].tolist() == hw[j][0].tolist() for j in range(8))
+        g = h.graph(); assert g["n"] == n and int(g["cnt0"].max()) <= g["m0"]
         h2 = h.clone(); h2.delete(5); del h2, h
+    # row-sharded search through the library's own RCCL communicator (world 1): create / sync / search / destroy
+    from vectorlite_amd.sharded import Comm, ShardedFlatIndex
+    if not os.environ.get("SOAK_NO_COMM"):
+        comm = Comm(Comm.unique_id(), 1, 0, 0)
+        sh = ShardedFlatIndex(idx, comm=comm)
+        si, ss, sn = sh.search_batch(Q[:16], 10, 0); searches += 16
+        assert si[0].tolist() == b[0][0].tolist() and ss[0].tolist() == b[1][0].tolist()
+        comm.close(); del sh, comm
     del idx, c
     gc.collect()
     torch.cuda.synchronize()
