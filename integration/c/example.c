@@ -1,6 +1,6 @@
 /* Plain-C caller of libvectorlite_amd.so: the reference's own flat-search test
  * (src/index/flat.rs:187-201: unit basis vectors, q = [1,0,0], k = 2 -> first id 1, score 1)
- * followed by a batched search and an HNSW round trip.  Doubles as the check that
+ * followed by a batched search, an HNSW round trip and a row-sharded batch over the library's own RCCL communicator.  Doubles as the check that
  * include/vectorlite_amd.h is valid C99 (tests/test_cabi_cpu.py compiles it with gcc -std=c99 -pedantic).
  *
  *   gcc -std=c99 -I include integration/c/example.c -L vectorlite_amd -lvectorlite_amd -Wl,-rpath,$PWD/vectorlite_amd -o example
@@ -87,6 +87,61 @@ int main(void)
     if (vl_index_search(hn, hq, 3, 2, VL_COSINE, ids, scores, &n) != VL_ERR_METRIC_MISMATCH) return 1;
     if (vl_index_delete(hn, 999) != VL_ERR_NOT_FOUND) return 1; /* "Vector ID 999 does not exist" */
     vl_index_destroy(hn);
+
+    /* row shards (north_star's config 3): this process is rank 0 of a world of 1 -- the same calls a rank of 8 makes.
+     * vl_comm_unique_id on rank 0, the 128 bytes to the others by the host's own channel, vl_comm_create everywhere
+     * (ncclCommInitRank), vl_shard_sync (each rank learns its row offset), then batches: local scan, ONE ncclAllGather
+     * of the per-shard top-k records inside the library, device merge.  The answer equals vl_index_search_batch on
+     * one index holding every shard's rows. */
+    {
+        enum { N = 9000, D = 8, NQ = 5, K = 4 };
+        static double srows[N][D];
+        static uint64_t sids[N];
+        uint64_t seed = 88172645463325252ull;
+        for (int i = 0; i < N; ++i) {
+            sids[i] = 1000 + (uint64_t)i;
+            for (int d = 0; d < D; ++d) {
+                seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17;      /* xorshift: any data will do */
+                srows[i][d] = (double)(seed % 2001) / 1000.0 - 1.0;
+            }
+        }
+        for (int d = 0; d < D; ++d) srows[7000][d] = srows[12][d];              /* an exact duplicate: position breaks the tie */
+        vl_index *shard = NULL;
+        CHECK(vl_flat_from_rows(D, sids, &srows[0][0], N, 0, &shard));
+        uint8_t id[VL_COMM_ID_BYTES];
+        vl_comm *comm = NULL;
+        CHECK(vl_comm_unique_id(id));
+        CHECK(vl_comm_create(id, /*world=*/1, /*rank=*/0, /*device=*/0, &comm));
+        uint64_t off = 99, total = 0;
+        CHECK(vl_shard_sync(shard, comm, &off, &total));
+        if (off != 0 || total != N || vl_comm_world(comm) != 1 || vl_comm_rank(comm) != 0) return 1;
+        double sq[NQ][D];
+        for (int q = 0; q < NQ; ++q)
+            for (int d = 0; d < D; ++d) sq[q][d] = srows[12 + 100 * q][d] * (q == 0 ? 1.0 : 1.01);
+        uint64_t gpos[NQ * K], gids[NQ * K], gn[NQ], lids[NQ * K], ln[NQ];
+        double gsc[NQ * K], lsc[NQ * K];
+        CHECK(vl_shard_search_batch(shard, comm, &sq[0][0], NQ, D, K, VL_EUCLIDEAN, gpos, gids, gsc, gn));
+        CHECK(vl_index_search_batch(shard, &sq[0][0], NQ, D, K, VL_EUCLIDEAN, lids, lsc, ln));
+        for (int q = 0; q < NQ; ++q) {
+            if (gn[q] != K || ln[q] != K) return 1;
+            for (int j = 0; j < K; ++j)
+                if (gids[q * K + j] != lids[q * K + j] || gsc[q * K + j] != lsc[q * K + j] || gids[q * K + j] != 1000 + gpos[q * K + j]) return 1;
+        }
+        printf("shards: query 0 -> ids %llu %llu (rows 12 and 7000 are equal: the earlier one first), scores %.17g %.17g\n",
+               (unsigned long long)gids[0], (unsigned long long)gids[1], gsc[0], gsc[1]);
+        if (gids[0] != 1012 || gids[1] != 8000 || gsc[0] != 1.0 || gsc[1] != 1.0) return 1;
+        /* a query of the wrong length fails on every rank alike (the status travels inside the exchange) */
+        if (vl_shard_search_batch(shard, comm, &sq[0][0], 1, D - 1, K, VL_EUCLIDEAN, gpos, gids, gsc, gn) != VL_ERR_DIM_MISMATCH) return 1;
+        /* a mutation without a re-sync is reported, not silently merged */
+        CHECK(vl_index_delete(shard, 1000));
+        if (vl_shard_search_batch(shard, comm, &sq[0][0], 1, D, K, VL_EUCLIDEAN, gpos, gids, gsc, gn) != VL_ERR_INVALID_ARG) return 1;
+        CHECK(vl_shard_sync(shard, comm, &off, &total));
+        if (total != N - 1) return 1;
+        CHECK(vl_shard_search_batch(shard, comm, &sq[0][0], 1, D, K, VL_EUCLIDEAN, gpos, gids, gsc, gn));
+        if (gn[0] != K || gids[0] != 1012 || gpos[0] != 11) return 1;          /* positions moved up by one */
+        vl_comm_destroy(comm);
+        vl_index_destroy(shard);
+    }
     printf("ok\n");
     return 0;
 }
