@@ -376,7 +376,7 @@ def test_batch_scan_kernel_parity(V, O, dim):
                 assert [int(ids[p]) for p in pos[i]] == ri.tolist()
 
 
-@pytest.mark.parametrize("dim,n", [(128, 9000), (384, 12000), (768, 8500), (700, 9001), (100, 4000), (384, 1500), (128, 8191), (128, 100000), (100, 9000)])
+@pytest.mark.parametrize("dim,n", [(128, 9000), (384, 12000), (768, 8500), (700, 9001), (100, 4000), (384, 1500), (128, 8191), (128, 100000), (100, 9000), (512, 9000), (450, 8300), (256, 20000)])
 def test_mfma_large_batch_parity(V, O, dim, n):
     """>= 2 queries per call on an index of >= 8192 rows take the bf16 MFMA candidate filter; results must still be
     the oracle's bit for bit, including queries the filter cannot certify (ties, out-of-domain)."""

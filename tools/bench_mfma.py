@@ -19,12 +19,13 @@ def main():
     ap.add_argument("--config", default="c5", choices=["c5", "c3"])
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--nq", type=int, default=0)
+    ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--check", type=int, default=32)
     a = ap.parse_args()
     rows, dim, nq, metric, name = ((10_000_000, 384, 4096, 0, "config 5: Q=4096 x N=10M x dim 384, cosine, k=10, 1 GPU") if a.config == "c5"
                                    else (1_250_000, 768, 1024, 1, "config 3, one rank's shard: 1024 queries x 1.25M x dim 768, Euclidean, k=10"))
-    rows, nq = a.rows or rows, a.nq or nq
+    rows, nq, dim = a.rows or rows, a.nq or nq, a.dim or dim
     import torch
     import vectorlite_amd as V
     dev = torch.device("cuda", 0)

@@ -495,7 +495,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
 constexpr int RS_NWAVES = RS_NWAVES_OVERRIDE;
 // queries per workgroup: 128 (two halves of 4 query blocks) while a query row fits LDS 128 times (dims <= 384);
 // 64 at dim 768, where a row block's K is walked in two phases instead (rs_qpb(), k_mfma_rows)
-constexpr int rs_qpb(uint32_t ldb) { return ldb <= 384 ? 128 : 64; }
+constexpr int rs_qpb(uint32_t ldb) { return ldb <= 512 ? 128 : 64; }
 constexpr int RS_SEG = 192;        // ring entries per wave
 
 
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     //   dims <= 384: the whole K stays in registers (PH = 1) and the 128 queries come in QH = 2 halves of 4 query blocks;
     //   dim 768:     K comes in PH = 2 phases of 12 K-steps (the same 96 fragment registers, refilled for the second
     //                phase while the first runs), the accumulators live through both, 64 queries (QH = 1).
-    constexpr int PH = (KSTEPS > 24) ? 2 : 1;
+    constexpr int PH = (KSTEPS > 32) ? 2 : 1;
     constexpr int QH = (PH == 1) ? 2 : 1;
     constexpr int HQB = 4;                    // query blocks (of 16) per sub-iteration
     constexpr int QPB = QH * HQB * 16;        // queries per workgroup
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     static_assert(KS32 % PH == 0 && QPB == rs_qpb(LDB), "K phases are whole steps; host and kernel agree on the chunk");
     // K-steps the query fragments are read ahead of their MFMAs.  The fragment buffers rotate with the position,
     // and the rotation must close over a row block (the loop over blocks re-enters at position 0): NB | NPOS.
-    constexpr int B_AHEAD = (NPOS % 3 == 0) ? 2 : 3;
+    constexpr int B_AHEAD = (KSP >= 16) ? 1 : ((NPOS % 3 == 0) ? 2 : 3);  // 16 K-steps of row fragments leave registers for one step ahead only
     constexpr int NB = B_AHEAD + 1;
     static_assert(NPOS % NB == 0, "the fragment-buffer rotation closes over one row block");
     static_assert(KSTEPS % 2 == 0, "whole 32-deep K steps");
@@ -1213,7 +1213,7 @@ bool mfma_rows_kernel(uint32_t dim)
 {
     const char* kv = getenv("VL_MFMA_KERNEL");
     const uint32_t ldb = mfma_ldb(dim);
-    return (ldb <= 384 || ldb == 768) && !(kv && kv[0] == 't');
+    return (ldb <= 512 || ldb == 768) && !(kv && kv[0] == 't');
 }
 
 hipError_t launch_rows_bf16_frag(hipStream_t s, const double* master_rows, uint64_t row0, uint64_t n, uint32_t dim,
@@ -1366,7 +1366,7 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
         else if (metric == EUCLIDEAN) VL_RLAUNCH2(K, EUCLIDEAN)   \
         else VL_RLAUNCH2(K, DOT)                                  \
     }
-            VL_RLAUNCH(8) VL_RLAUNCH(16) VL_RLAUNCH(24) VL_RLAUNCH(48)
+            VL_RLAUNCH(8) VL_RLAUNCH(16) VL_RLAUNCH(24) VL_RLAUNCH(32) VL_RLAUNCH(48)
 #undef VL_RLAUNCH
 #undef VL_RLAUNCH2
             if (!r_launched) return hipErrorInvalidValue;

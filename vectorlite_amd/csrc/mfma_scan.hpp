@@ -49,7 +49,7 @@ bool mfma_scan_supported(uint32_t dim, int metric);
 hipError_t launch_rows_bf16(hipStream_t s, const double* master, uint64_t n, uint32_t dim, void* out_bf16,
                             float* out_norm, float* out_sqnorm);
 
-// Dimensions up to 384 (bf16 row stride <= 384) take the row-stationary kernel k_mfma_rows, which reads a FRAGMENT-MAJOR
+// Every bf16 row stride with an MFMA shape (128 / 256 / 384 / 512 / 768) takes the row-stationary kernel k_mfma_rows, which reads a FRAGMENT-MAJOR
 // bf16 slab (launch_rows_bf16_frag); VL_MFMA_KERNEL=tile keeps the LDS-tile kernel k_mfma_scan and its row-major slab.
 bool mfma_rows_kernel(uint32_t dim);
 // rows [row0, row0 + n) of the index (master_rows = their f64 rows) -> the fragment-major slab and the two per-row arrays,
