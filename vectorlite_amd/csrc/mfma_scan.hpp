@@ -13,7 +13,10 @@ namespace vl {
 constexpr int MFMA_GROUPS = 256;       // workgroups (= row groups) of the sampling pass
 constexpr int MFMA_CAND_CAP = 4096;    // candidate buffer entries per query
 constexpr int MFMA_MAX_BATCH = 2048;   // queries per launch sequence (scratch is sized for this: ~70 MB per workspace);
-                                       // config 5's 4096 queries are two sequences: half the fixed launches of four
+                                       // config 5's 4096 queries are two sequences: half the fixed launches of four.
+                                       // Not 4096: 32 query chunks leave the sampling pass 8 workgroups per chunk = 64 groups,
+                                       // and the 64th largest of 64 group maxima is far too loose a threshold (every
+                                       // candidate buffer overflowed and all queries fell back: measured)
 // Fewer rows than this (MFMA_GROUPS tiles of 32) leave the sampling pass with fewer than 64 groups: no
 // threshold, every score a candidate, guaranteed buffer overflow -- such indexes take the f32 batch path.
 constexpr uint64_t MFMA_MIN_ROWS = (uint64_t)MFMA_GROUPS * 32;
