@@ -160,3 +160,22 @@ def test_headline_10m_x_384_fast_equals_exact_and_batch_equals_single(V):
     v = idx.get_vector(int(ids_for(probe, 1)[0])).values
     r = idx.search(v, 1, 0)
     assert r[0].id == int(ids_for(probe, 1)[0]) and abs(r[0].score - 1.0) < 1e-12
+
+
+def test_dim768_batch_of_2048_runs_as_two_sequences_on_the_mfma_filter(V):
+    """At stride 768 a launch sequence takes 1024 queries (16 chunks of 64: the sampling pass needs >= 128 groups);
+    2048 queries must therefore be TWO filter sequences -- not one with degenerate thresholds and 2048 fallbacks."""
+    n, dim, nq, k = 300_000, 768, 2048, 10
+    idx = device_index(V, n, dim, seed=5, chunk=100_000)
+    Q = unit_rows(np.random.default_rng(77), nq, dim)
+    idx.search_batch(Q[:64], k, 1)
+    idx.profile_read()
+    idx.profile_enable(True)
+    bi, bs, bn = idx.search_batch(Q, k, 1)
+    idx.profile_enable(False)
+    passes = idx.profile_read()[0]
+    assert passes <= 2 + 8, passes          # two sequences (+ a few queries redone one by one at most)
+    assert bn.tolist() == [k] * nq
+    for qi in list(range(0, nq, 97)) + [1023, 1024, 2047]:
+        si, ss = idx.search_arrays(Q[qi], k, 1)
+        assert bi[qi].tolist() == si.tolist() and bs[qi].tolist() == ss.tolist(), qi

@@ -1083,9 +1083,10 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, uint64
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count();
     };
-    for (uint64_t q0 = 0; q0 < nq; q0 += MFMA_MAX_BATCH) {
+    const uint64_t seq = mfma_sequence_queries((uint32_t)dim_);
+    for (uint64_t q0 = 0; q0 < nq; q0 += seq) {
         const auto t_0 = now();
-        const uint32_t g = (uint32_t)std::min<uint64_t>(MFMA_MAX_BATCH, nq - q0);
+        const uint32_t g = (uint32_t)std::min<uint64_t>(seq, nq - q0);
         double* norms = ws->mf_h_q64 + (size_t)g * dim_;
         std::vector<uint8_t> in_domain(g);
         for (uint32_t j = 0; j < g; ++j)

@@ -1209,6 +1209,12 @@ hipError_t launch_rows_bf16(hipStream_t s, const double* master, uint64_t n, uin
     return hipGetLastError();
 }
 
+uint32_t mfma_sequence_queries(uint32_t dim)
+{
+    if (!mfma_rows_kernel(dim)) return 1024;  // the LDS-tile kernel: 4 chunks of 256
+    return std::min<uint32_t>((uint32_t)MFMA_MAX_BATCH, 16u * (uint32_t)rs_qpb(mfma_ldb(dim)));
+}
+
 bool mfma_rows_kernel(uint32_t dim)
 {
     const char* kv = getenv("VL_MFMA_KERNEL");
@@ -1315,6 +1321,10 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
             // sampling pass: the grid of pass 1 (every CU busy, one round), each workgroup reporting gpw groups so that
             // k_thresholds sees up to MFMA_GROUPS of them (>= 64 as soon as the sample holds 64 blocks)
             uint32_t gx0 = std::max<uint32_t>(1u, std::min<uint32_t>({(sample_blocks + RS_NWAVES - 1) / RS_NWAVES, wg_cap, (uint32_t)MFMA_GROUPS}));
+            // never fewer than 128 groups when the sample has the blocks for them (the 64th largest of 64 group maxima is
+            // the smallest of them: a threshold so loose that every candidate buffer overflows); more workgroups than are
+            // co-resident just queue up
+            if (gx0 * RS_NWAVES < 128u) gx0 = std::max<uint32_t>(gx0, std::min<uint32_t>(16u, (sample_blocks + RS_NWAVES - 1) / RS_NWAVES));
             uint32_t r_gpw = 1;
             while (r_gpw < (uint32_t)RS_NWAVES && gx0 * r_gpw * 2 <= (uint32_t)MFMA_GROUPS) r_gpw *= 2;
             if (sample_blocks < gx0 * r_gpw) {  // tiny sample: one block per group at most

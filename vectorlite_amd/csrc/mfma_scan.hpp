@@ -47,6 +47,11 @@ struct MfmaScratch {
 
 bool mfma_scan_supported(uint32_t dim, int metric);
 
+// Queries one launch sequence answers for this dimension (<= MFMA_MAX_BATCH): the sampling pass must hand k_thresholds
+// at least 128 groups, i.e. 16 workgroups of 8 waves per query chunk -- at most 16 co-resident chunks on 256 CUs:
+// 16 x 128 queries up to stride 512, 16 x 64 at stride 768.
+uint32_t mfma_sequence_queries(uint32_t dim);
+
 // f64 master rows [n, dim] -> UNIT-NORMALISED bf16 rows [n, ldb] (x/|x| in f64 -> f32 -> bf16, round to
 // nearest even), |row| and |row|^2 (f64, rounded once to f32)
 hipError_t launch_rows_bf16(hipStream_t s, const double* master, uint64_t n, uint32_t dim, void* out_bf16,
