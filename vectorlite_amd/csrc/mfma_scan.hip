@@ -579,8 +579,13 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
 
     // block schedule: neighbouring WORKGROUPS stream neighbouring 32-row blocks (block = begin + x + gridDim.x * (wave + 8 i)),
     // so in MODE 0 every workgroup (= group) owns rows as soon as there are gridDim.x blocks
+#ifdef RS_DBG_PAIRLOAD  // diagnostic: waves w and w + 4 (SIMD partners) stream the SAME blocks -- do their loads share L1?
+    const uint32_t stride = gridDim.x * (RS_NWAVES / 2);
+    uint32_t b = blk_begin + blockIdx.x + gridDim.x * (uint32_t)(wave & 3);
+#else
     const uint32_t stride = gridDim.x * RS_NWAVES;
     uint32_t b = blk_begin + blockIdx.x + gridDim.x * (uint32_t)wave;
+#endif
     const bool has_work = b < blk_end;
     const uint32_t b_last = has_work ? b + ((blk_end - 1 - b) / stride) * stride : blk_begin;  // a valid block to re-read at the tail
 
