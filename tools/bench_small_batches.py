@@ -22,7 +22,7 @@ idx.search_batch(Q[:64], 10, 0); idx.search_batch(Q[:64], 10, 0)
 t0 = time.perf_counter()
 for i in range(20): idx.search_arrays(Q[i], 10, 0)
 print(f"single search(): {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms")
-for nq in (2, 4, 8, 16, 32, 64, 128, 129, 256, 512, 1024, 2048):
+for nq in (2, 4, 8, 16, 32, 64, 128, 129, 256, 384, 512, 640, 768, 896, 1024, 1280, 1408, 2048):  # 384 = 3 chunks of 128, 640 = 5, ...
     idx.search_batch(Q[:nq], 10, 0)
     idx.profile_read(); idx.profile_enable(True)
     t0 = time.perf_counter()

@@ -493,10 +493,26 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_scan(const __bf16* __restr
 #define RS_NWAVES_OVERRIDE 8
 #endif
 constexpr int RS_NWAVES = RS_NWAVES_OVERRIDE;
-// queries per workgroup: 128 (two halves of 4 query blocks) while a query row fits LDS 128 times (dims <= 384);
-// 64 at dim 768, where a row block's K is walked in two phases instead (rs_qpb(), k_mfma_rows)
-constexpr int rs_qpb(uint32_t ldb) { return ldb <= 512 ? 128 : 64; }
-constexpr int RS_SEG = 192;        // ring entries per wave
+// queries per workgroup: 128 (two halves of 4 query blocks) while a query row fits LDS 128 times (strides <= 512);
+// 96 at stride 768 (147 of the 160 KB: all that fits), where a row block's K is walked in phases (rs_qpb(), k_mfma_rows).
+// Every query block more is one more pair of MFMAs per row fragment a wave pulls in, and fewer query chunks re-reading
+// the slab from L2.  Measured on the 1.25 M x 768 shard (1024 queries, Euclidean, the two pass-1 stages, same box):
+//   64 queries, 2 phases of 12 K-steps (round 2's first shape) ... 1845 us
+//   80 queries, 2 phases ........................................ 1710-1770 us
+//   96 queries, 3 phases of 8 ................................... 1700 us
+//   96 queries, 4 phases of 6 ................................... 1605-1630 us   <- shipped
+//   96 queries, 6 phases of 4 ................................... 1577-1607 us
+// (96 queries with 2 phases spill in the Euclidean epilogue: 96 fragment + 48 accumulator + 48 query-fragment registers.)
+// The K-steps of row fragments a wave holds (= its loads in flight: 24 KB at 2 phases, 8 KB at 6) make no difference.
+#ifndef RS_HQB768
+#define RS_HQB768 6
+#endif
+#ifndef RS_PH768
+#define RS_PH768 4
+#endif
+constexpr int rs_qpb(uint32_t ldb) { return ldb <= 512 ? 128 : 16 * RS_HQB768; }
+// ring entries per wave: 192, or 128 where the queries leave less LDS
+constexpr int rs_seg(uint32_t ldb) { return (size_t)rs_qpb(ldb) * (ldb * 2 + 32) + 8 * 192 * 10 + 1024 <= 160 * 1024 ? 192 : 128; }
 
 
 template <int KSTEPS, int MODE, int METRIC>
@@ -516,11 +532,11 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     constexpr int NT = RS_NWAVES * 64;
     // A row block is worked off in NU sub-iterations that all reuse the KSP row fragments a wave holds:
     //   dims <= 384: the whole K stays in registers (PH = 1) and the 128 queries come in QH = 2 halves of 4 query blocks;
-    //   dim 768:     K comes in PH = 2 phases of 12 K-steps (the same 96 fragment registers, refilled for the second
-    //                phase while the first runs), the accumulators live through both, 64 queries (QH = 1).
-    constexpr int PH = (KSTEPS > 32) ? 2 : 1;
+    //   dim 768:     K comes in PH phases of KSP K-steps (the fragment registers are refilled for the next phase while
+    //                one runs), the accumulators live through all of them, 16 RS_HQB768 queries (QH = 1).
+    constexpr int PH = (KSTEPS > 32) ? RS_PH768 : 1;
     constexpr int QH = (PH == 1) ? 2 : 1;
-    constexpr int HQB = 4;                    // query blocks (of 16) per sub-iteration
+    constexpr int HQB = (PH > 1) ? RS_HQB768 : 4;  // query blocks (of 16) per sub-iteration
     constexpr int QPB = QH * HQB * 16;        // queries per workgroup
     constexpr int QB = QPB / 16;
     constexpr int KSP = KS32 / PH;            // K-steps per phase = row fragments held per 16-row block
@@ -529,10 +545,17 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     static_assert(KS32 % PH == 0 && QPB == rs_qpb(LDB), "K phases are whole steps; host and kernel agree on the chunk");
     // K-steps the query fragments are read ahead of their MFMAs.  The fragment buffers rotate with the position,
     // and the rotation must close over a row block (the loop over blocks re-enters at position 0): NB | NPOS.
-    constexpr int B_AHEAD = (KSP >= 16) ? 1 : ((NPOS % 3 == 0) ? 2 : 3);  // 16 K-steps of row fragments leave registers for one step ahead only
+    // (16 K-steps of row fragments leave registers for one step ahead only; with 5 or 6 query blocks one step is 10-12
+    // MFMAs = 160-192 cycles, more than the LDS latency already)
+#ifdef RS_BAHEAD
+    constexpr int B_AHEAD = RS_BAHEAD;
+#else
+    constexpr int B_AHEAD = (KSP >= 16 || HQB >= 5) ? 1 : ((NPOS % 3 == 0) ? 2 : 3);
+#endif
     constexpr int NB = B_AHEAD + 1;
     static_assert(NPOS % NB == 0, "the fragment-buffer rotation closes over one row block");
     static_assert(KSTEPS % 2 == 0, "whole 32-deep K steps");
+    constexpr int RS_SEG = rs_seg(LDB);
     constexpr int RING = (MODE == 1) ? RS_NWAVES * RS_SEG : 1;
 
     __shared__ __attribute__((aligned(16))) unsigned char q_lds[QPB * LDS_ROW];
@@ -548,7 +571,26 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: block numbers, row bases
                                                                 // and the partial-block branch live in scalar registers
     const int c16 = lane & 15, kg = lane >> 4;
-    const uint32_t chunk_base = blockIdx.y * QPB;
+    // ---- which (row-block lane x, query chunk y) this workgroup is: XCD-aware ----
+    // Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  All the chunks of one x stream the
+    // SAME row blocks, so they belong on ONE XCD (its L2 then fetches a block from HBM once and serves the other chunks);
+    // with id = x + gridDim.x y that only happens when 8 divides gridDim.x (11 chunks x 23: every XCD fetched every
+    // block, 2.7 instead of 1.5 ms).  So the XCD's workgroups, in order, take a contiguous range of the (x, y) pairs
+    // sorted by x: at most 7 of the x straddle two XCDs, whatever the grid.
+#ifndef RS_NO_XCD_REMAP
+    uint32_t bx, by;
+    {
+        const uint32_t ny = gridDim.y, total = gridDim.x * ny;
+        const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7u;
+        uint32_t p = lin >> 3;
+        for (uint32_t c = 0; c < xcd; ++c) p += (total - c + 7u) >> 3;  // workgroups of the XCDs before this one
+        bx = p / ny;
+        by = p - bx * ny;
+    }
+#else
+    const uint32_t bx = blockIdx.x, by = blockIdx.y;
+#endif
+    const uint32_t chunk_base = by * QPB;
 
     // ---- the workgroup's queries -> LDS (the only barrier of the kernel besides MODE 0's final combine) ----
     {
@@ -581,10 +623,10 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     // so in MODE 0 every workgroup (= group) owns rows as soon as there are gridDim.x blocks
 #ifdef RS_DBG_PAIRLOAD  // diagnostic: waves w and w + 4 (SIMD partners) stream the SAME blocks -- do their loads share L1?
     const uint32_t stride = gridDim.x * (RS_NWAVES / 2);
-    uint32_t b = blk_begin + blockIdx.x + gridDim.x * (uint32_t)(wave & 3);
+    uint32_t b = blk_begin + bx + gridDim.x * (uint32_t)(wave & 3);
 #else
     const uint32_t stride = gridDim.x * RS_NWAVES;
-    uint32_t b = blk_begin + blockIdx.x + gridDim.x * (uint32_t)wave;
+    uint32_t b = blk_begin + bx + gridDim.x * (uint32_t)wave;
 #endif
     const bool has_work = b < blk_end;
     const uint32_t b_last = has_work ? b + ((blk_end - 1 - b) / stride) * stride : blk_begin;  // a valid block to re-read at the tail
@@ -606,13 +648,17 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
             if (METRIC == EUCLIDEAN) aux2[rb] = *reinterpret_cast<const f32x4*>(row_sqn + r0);
         }
     };
+    // per-row scalars: PH = 1 loads a block's with the last fragments of the block before (they are needed after the
+    // first half already) and keeps a copy while the next ones arrive; with K phases they are fetched when the block's
+    // LAST phase starts -- one set of registers instead of two, half the registers, next to 6 query blocks of accumulators
+    constexpr bool AUX_JIT = PH > 1;
     if (has_work) {
         const unsigned char* p = a_ptr(b);
 #pragma unroll
         for (int s = 0; s < KSP; ++s)
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) afrag[rb][s] = *reinterpret_cast<const bf16x8*>(p + rb * (16 * ROW_BYTES) + s * 1024);
-        load_aux(b);
+        if (!AUX_JIT) load_aux(b);
     }
 
     // query fragments: position i = (sub-iteration u, step s) reads 4 query blocks at one K-step --
@@ -621,7 +667,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     bf16x8 bq[NB][HQB];
     auto read_b = [&](int i, bf16x8(&dst)[HQB]) {
         const int u = (i / KSP) % NU, s = i % KSP;
-        const int qb0 = (QH == 2) ? u * HQB : 0, kstep = (PH == 2) ? u * KSP + s : s;
+        const int qb0 = (QH == 2) ? u * HQB : 0, kstep = (PH > 1) ? u * KSP + s : s;
 #pragma unroll
         for (int j = 0; j < HQB; ++j)
             dst[j] = *reinterpret_cast<const bf16x8*>(qrow + (qb0 + j) * 16 * LDS_ROW + kstep * 64);
@@ -642,7 +688,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
                 cand[(size_t)qq * cap + slot] = c;
             }
         }
-        if (my_cnt > (uint32_t)RS_SEG) {  // the segment overflowed: candidates of any of the 128 queries may be lost -> host redoes them
+        if (my_cnt > (uint32_t)RS_SEG) {  // the segment overflowed: candidates of any of the workgroup's queries may be lost -> host redoes them
             for (uint32_t j = lane; j < (uint32_t)QPB; j += 64)
                 if (chunk_base + j < nq) atomicAdd(&cnt[chunk_base + j], cap + 1u);
         }
@@ -673,12 +719,16 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
             asm volatile("" : "+v"(afrag[1][s2]));
         }
 #endif
-        f32x4 aux_c[2], aux2_c[2];                 // this block's per-row scalars (the registers are reloaded below)
+        f32x4 aux_cp[2], aux2_cp[2];               // PH = 1: this block's per-row scalars (the registers are reloaded below)
+        if (!AUX_JIT) {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            aux_c[rb] = (METRIC != COSINE) ? aux[rb] : f32x4{1.f, 1.f, 1.f, 1.f};
-            aux2_c[rb] = (METRIC == EUCLIDEAN) ? aux2[rb] : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int rb = 0; rb < 2; ++rb) {
+                aux_cp[rb] = (METRIC != COSINE) ? aux[rb] : f32x4{1.f, 1.f, 1.f, 1.f};
+                aux2_cp[rb] = (METRIC == EUCLIDEAN) ? aux2[rb] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
+        auto& aux_c = AUX_JIT ? aux : aux_cp;
+        auto& aux2_c = AUX_JIT ? aux2 : aux2_cp;
         f32x4 acc[2][HQB];
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -691,9 +741,9 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
             }
             // last use of the fragments a wave holds: PH = 1 in the last half (refill for the next block); PH = 2 in
             // BOTH phases (phase 0 refills with this block's second K half, phase 1 with the next block's first)
-            constexpr bool ALWAYS_RELOAD = PH == 2;
+            constexpr bool ALWAYS_RELOAD = PH > 1;
             const bool reload = ALWAYS_RELOAD || u == NU - 1;
-            const unsigned char* psrc = (PH == 2 && u == 0) ? pc + (size_t)KSP * 1024 : pn;
+            const unsigned char* psrc = (PH > 1 && u < PH - 1) ? pc + (size_t)(u + 1) * KSP * 1024 : pn;
 #pragma unroll
             for (int s = 0; s < KSP; ++s) {
                 const int i = u * KSP + s;
@@ -718,8 +768,9 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb)
                         afrag[rb][s] = *reinterpret_cast<const bf16x8*>(psrc + rb * (16 * ROW_BYTES) + s * 1024);
-                    if (u == NU - 1 && s == KSP - 1) load_aux(nb);
+                    if (!AUX_JIT && u == NU - 1 && s == KSP - 1) load_aux(nb);
                 }
+                if (AUX_JIT && u == NU - 1 && s == 0) load_aux(b);
 #endif
 #ifndef RS_INTERLEAVE_OFF
 #pragma unroll
@@ -779,12 +830,15 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
                     for (int j = 0; j < HQB; ++j) run_max[half * HQB + j] = max3f(run_max[half * HQB + j], mj[j], mj[j]);
                     return;
                 }
-                // ONE test and ONE branch for the 4 query blocks of the sub-iteration: does any key reach its query's
+                // ONE test and ONE branch for the HQB query blocks of the sub-iteration: does any key reach its query's
                 // threshold?  (m - T >= 0; T = +inf for padding queries gives -inf, a fully masked block gives -inf or NaN)
                 float ex[HQB];
 #pragma unroll
                 for (int j = 0; j < HQB; ++j) ex[j] = mj[j] - thr_q[half * HQB + j];
-                const float any = max3f(max3f(ex[0], ex[1], ex[2]), ex[3], ex[3]);
+                float any = ex[0];
+#pragma unroll
+                for (int j = 1; j + 1 < HQB; j += 2) any = max3f(any, ex[j], ex[j + 1]);
+                if (HQB % 2 == 0) any = max3f(any, ex[HQB - 1], ex[HQB - 1]);
                 if (__builtin_amdgcn_ballot_w64(any >= 0.0f) == 0ull) return;
                 // rare; only THIS wave pays for it
 #pragma unroll
@@ -848,7 +902,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
         }
         __syncthreads();
         for (uint32_t c = tid; c < gpw * (uint32_t)QPB; c += NT) {
-            const uint32_t gl = c / QPB, ql = c % QPB, gidx = blockIdx.x * gpw + gl;
+            const uint32_t gl = c / QPB, ql = c % QPB, gidx = bx * gpw + gl;
             if (chunk_base + ql < nq && gidx < n_groups) gmax[(size_t)(chunk_base + ql) * n_groups + gidx] = gmax_lds[c];
         }
     }
