@@ -1391,22 +1391,31 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
                 gx0 = std::max<uint32_t>(1u, (sample_blocks + RS_NWAVES - 1) / RS_NWAVES);
             }
             const uint32_t r_groups = gx0 * r_gpw;
-            uint32_t st_end[4] = {0, n_blocks, n_blocks, n_blocks};
+            // Pass 1 in stages of growing size; between stages every query's threshold is tightened to its 64th best
+            // candidate so far (k_refine_thresholds).  The candidate code is not free (ballots, ring writes: the wave
+            // leaves the MFMA stream for hundreds of cycles), and how often a wave enters it is set by the threshold: with the
+            // sampled one about 64 x (stage rows / sample rows) rows per query pass, after a refine 64 x (stage rows /
+            // rows scanned so far).  So the first stage is short and the stages grow geometrically -- 1/16, 3/16, 7/16 of
+            // the blocks on long scans (>= 4 M rows), where a refine launch (~50 us with its gaps) is noise; a shard of
+            // ~1 M rows (config 3) is fastest with two (measured: 2.015 -> 1.953 ms at 1.25 M x 768, 1024 queries).
+            uint32_t st_end[5] = {0, n_blocks, n_blocks, n_blocks, n_blocks};
             int r_stages = 1;
             {
                 const char* se = getenv("VL_MFMA_STAGES");
-                // three stages pay for their second refine launch (~50 us with its gaps) only on long scans; a shard of
-                // ~1 M rows (config 3) is 3 % faster with two (measured: 2.015 -> 1.953 ms at 1.25 M x 768, 1024 queries)
-                const int want = se && *se ? atoi(se) : (n_blocks >= 131072u ? 3 : 2);
+                const int want = se && *se ? atoi(se) : (n_blocks >= 131072u ? 4 : 2);
                 if (want >= 2 && n_blocks >= 128u * RS_NWAVES * wg_cap) {
-                    r_stages = want >= 3 ? 3 : 2;
-                    const char* s1 = getenv("VL_MFMA_STAGE1");
-                    const char* s2 = getenv("VL_MFMA_STAGE2");
-                    const uint32_t f1 = s1 && *s1 ? (uint32_t)atoi(s1) : (r_stages == 3 ? 3u : 2u);  // sixteenths
-                    const uint32_t f2 = s2 && *s2 ? (uint32_t)atoi(s2) : 7u;
-                    st_end[1] = (uint32_t)((uint64_t)n_blocks * f1 / 16);
-                    st_end[2] = r_stages == 3 ? (uint32_t)((uint64_t)n_blocks * f2 / 16) : n_blocks;
-                    st_end[3] = n_blocks;
+                    r_stages = want >= 4 ? 4 : want;
+                    static const uint32_t dflt[5][3] = {{0, 0, 0}, {0, 0, 0}, {2, 0, 0}, {3, 7, 0}, {1, 3, 7}};  // sixteenths
+                    static const char* const names[3] = {"VL_MFMA_STAGE1", "VL_MFMA_STAGE2", "VL_MFMA_STAGE3"};
+                    uint32_t prev = 0;
+                    for (int st = 1; st < r_stages; ++st) {
+                        const char* sv = getenv(names[st - 1]);
+                        uint32_t f = sv && *sv ? (uint32_t)atoi(sv) : dflt[r_stages][st - 1];
+                        f = std::min<uint32_t>(std::max<uint32_t>(f, prev), 16u);  // stage ends never go backwards
+                        st_end[st] = (uint32_t)((uint64_t)n_blocks * f / 16);
+                        prev = f;
+                    }
+                    st_end[r_stages] = n_blocks;
                 }
             }
             bool r_launched = false;
