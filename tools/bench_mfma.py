@@ -63,7 +63,7 @@ def main():
         "ms_per_batch": round(wall * 1e3, 3), "filter_kernels_ms_per_batch": round(kern * 1e3, 3),
         "passes_per_batch": n_pass // max(a.reps, 1),
         "roofline": {"bound": "mfma", "achieved": round(flops / kern / 1e12, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(flops / kern / 1e12 / PEAK_TFLOPS, 4), "kernel": "k_mfma_rows passes 0+1 (+ thresholds, candidate select); k_mfma_scan for bf16 row strides without a rows shape (512)",
+                     "frac": round(flops / kern / 1e12 / PEAK_TFLOPS, 4), "kernel": "k_mfma_rows: sampling pass + pass-1 stages (+ thresholds, refines, candidate select)",
                      "flops_per_batch": flops, "traffic": None,
                      "whole_call": {"achieved": round(flops / wall / 1e12, 1), "frac": round(flops / wall / 1e12 / PEAK_TFLOPS, 4)}},
         "parity": f"{ok}/{ns} sampled rows identical to single search() (ids and f64 scores)",
