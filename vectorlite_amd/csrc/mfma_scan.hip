@@ -17,6 +17,7 @@
 //     with the bf16 input-rounding term (2^-8 relative per operand) in the bound.
 // A query whose check fails (or whose buffer overflows) is redone on the f32 path by the host.
 #include "mfma_scan.hpp"
+#include "xcd_map.hpp"
 
 #include <stdlib.h>
 
@@ -571,22 +572,13 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: block numbers, row bases
                                                                 // and the partial-block branch live in scalar registers
     const int c16 = lane & 15, kg = lane >> 4;
-    // ---- which (row-block lane x, query chunk y) this workgroup is: XCD-aware ----
-    // Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  All the chunks of one x stream the
-    // SAME row blocks, so they belong on ONE XCD (its L2 then fetches a block from HBM once and serves the other chunks);
-    // with id = x + gridDim.x y that only happens when 8 divides gridDim.x (11 chunks x 23: every XCD fetched every
-    // block, 2.7 instead of 1.5 ms).  So the XCD's workgroups, in order, take a contiguous range of the (x, y) pairs
-    // sorted by x: at most 7 of the x straddle two XCDs, whatever the grid.
+    // ---- which (row-block lane x, query chunk y) this workgroup is: XCD-aware (xcd_map.hpp) ----
+    // All the chunks of one x stream the SAME row blocks, so they belong on ONE XCD (its L2 then fetches a block from HBM
+    // once and serves the other chunks); with id = x + gridDim.x y that only happens when 8 divides gridDim.x (11 chunks
+    // x 23: every XCD fetched every block, 2.7 instead of 1.5 ms).
 #ifndef RS_NO_XCD_REMAP
     uint32_t bx, by;
-    {
-        const uint32_t ny = gridDim.y, total = gridDim.x * ny;
-        const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7u;
-        uint32_t p = lin >> 3;
-        for (uint32_t c = 0; c < xcd; ++c) p += (total - c + 7u) >> 3;  // workgroups of the XCDs before this one
-        bx = p / ny;
-        by = p - bx * ny;
-    }
+    xcd_pair(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y, bx, by);
 #else
     const uint32_t bx = blockIdx.x, by = blockIdx.y;
 #endif
