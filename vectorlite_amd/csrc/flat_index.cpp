@@ -1050,16 +1050,18 @@ int GpuFlatIndex::ensure_mfma_scratch(Workspace* ws) const
     if (ws->mf.nq_cap) return OK;
     const size_t nqc = MFMA_MAX_BATCH;
     const uint32_t ldb = mfma_ldb((uint32_t)dim_);
-    VL_HIP(hipMalloc(&ws->mf.q_bf16, nqc * ldb * 2));
+    const size_t nqp = nqc + 256;  // whole query chunks (128 / 96 / 256 queries) past the last query
+    VL_HIP(hipMalloc(&ws->mf.q_bf16, nqp * ldb * 2));
     VL_TRY(dev_alloc(&ws->mf.gmax, nqc * MFMA_GROUPS));
     VL_TRY(dev_alloc(&ws->mf.thr, nqc));
     VL_TRY(dev_alloc(&ws->mf.cand, nqc * MFMA_CAND_CAP));
-    VL_TRY(dev_alloc(&ws->mf.cnt, nqc));
+    VL_TRY(dev_alloc(&ws->mf.cnt, nqp));
     VL_TRY(dev_alloc(&ws->mf_d_q64, nqc * (dim_ + 1)));
     VL_TRY(pinned_alloc(&ws->mf_h_q64, nqc * (dim_ + 1)));
     VL_TRY(dev_alloc(&ws->mf_lists, nqc * KP));
     VL_TRY(pinned_alloc(&ws->mf_h_result, nqc));
     ws->mf.nq_cap = (uint32_t)nqc;
+    ws->mf.nq_pad_cap = (uint32_t)nqp;
     return OK;
 }
 

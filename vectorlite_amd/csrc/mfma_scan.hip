@@ -511,7 +511,10 @@ constexpr int RS_NWAVES = RS_NWAVES_OVERRIDE;
 #ifndef RS_PH768
 #define RS_PH768 4
 #endif
-constexpr int rs_qpb(uint32_t ldb) { return ldb <= 512 ? 128 : 16 * RS_HQB768; }
+#ifndef RS_HQB1
+#define RS_HQB1 4   // query blocks per half while the whole K stays in registers (strides <= 384 could hold 6: see the anatomy file)
+#endif
+constexpr int rs_qpb(uint32_t ldb) { return ldb <= 384 ? 32 * RS_HQB1 : (ldb <= 512 ? 128 : 16 * RS_HQB768); }
 // ring entries per wave: 192, or 128 where the queries leave less LDS
 constexpr int rs_seg(uint32_t ldb) { return (size_t)rs_qpb(ldb) * (ldb * 2 + 32) + 8 * 192 * 10 + 1024 <= 160 * 1024 ? 192 : 128; }
 
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     //                one runs), the accumulators live through all of them, 16 RS_HQB768 queries (QH = 1).
     constexpr int PH = (KSTEPS > 32) ? RS_PH768 : 1;
     constexpr int QH = (PH == 1) ? 2 : 1;
-    constexpr int HQB = (PH > 1) ? RS_HQB768 : 4;  // query blocks (of 16) per sub-iteration
+    constexpr int HQB = (PH > 1) ? RS_HQB768 : (LDB <= 384 ? RS_HQB1 : 4);  // query blocks (of 16) per sub-iteration
     constexpr int QPB = QH * HQB * 16;        // queries per workgroup
     constexpr int QB = QPB / 16;
     constexpr int KSP = KS32 / PH;            // K-steps per phase = row fragments held per 16-row block
@@ -1298,7 +1301,7 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     const int nwaves = shape / 10, qt = shape == 82 ? 1 : shape % 10;
     const uint32_t qpb = (uint32_t)(shape == 82 ? nwaves / 2 : nwaves) * 32 * (uint32_t)qt;
     const uint32_t nq_pad = (nq + qpb - 1) / qpb * qpb;
-    if (nq_pad > w.nq_cap) return hipErrorInvalidValue;
+    if (nq_pad > w.nq_pad_cap) return hipErrorInvalidValue;
     // the 8-wave shape works on 64-row tiles (two 32-row MFMA blocks per barrier), the others on 32-row tiles
     // (up to d = 384; at 512 the eight 16-byte pieces per thread of a 64-row tile spill)
     const uint32_t tile_rows = (shape == 81 && ldb <= 384) ? 2u * MF_ROWS : (uint32_t)MF_ROWS;
@@ -1349,7 +1352,7 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
         if (mfma_rows_kernel(dim)) {  // slab_bf16 is then the fragment-major slab (launch_rows_bf16_frag)
             const uint32_t rq = (uint32_t)rs_qpb(ldb);
             const uint32_t rnq_pad = (nq + rq - 1) / rq * rq;
-            if (rnq_pad > w.nq_cap) return hipErrorInvalidValue;
+            if (rnq_pad > w.nq_pad_cap) return hipErrorInvalidValue;
             const uint32_t r_chunks = rnq_pad / rq;
             {
                 const size_t total = (size_t)rnq_pad * ldb;

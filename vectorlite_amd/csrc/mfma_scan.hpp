@@ -37,12 +37,13 @@ inline uint32_t mfma_ldb(uint32_t dim)
 }
 
 struct MfmaScratch {
-    void* q_bf16 = nullptr;     // [nq_cap_pad, ldb] bf16
-    int* gmax = nullptr;        // [nq_cap_pad, MFMA_GROUPS]
-    float* thr = nullptr;       // [nq_cap_pad]
-    Cand32* cand = nullptr;     // [nq_cap_pad, MFMA_CAND_CAP]
-    uint32_t* cnt = nullptr;    // [nq_cap_pad]
-    uint32_t nq_cap = 0;
+    void* q_bf16 = nullptr;     // [nq_pad_cap, ldb] bf16
+    int* gmax = nullptr;        // [nq_cap, MFMA_GROUPS]
+    float* thr = nullptr;       // [nq_cap]
+    Cand32* cand = nullptr;     // [nq_cap, MFMA_CAND_CAP]
+    uint32_t* cnt = nullptr;    // [nq_pad_cap]
+    uint32_t nq_cap = 0;        // queries per launch sequence the buffers hold
+    uint32_t nq_pad_cap = 0;    // ... rounded up to whole query chunks: rows of q_bf16 and cnt (the padding queries never produce candidates)
 };
 
 bool mfma_scan_supported(uint32_t dim, int metric);
