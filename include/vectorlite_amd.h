@@ -222,6 +222,17 @@ int vl_index_search_batch_positions(const vl_index *h, const double *queries, ui
                                     uint64_t k, int metric, uint64_t *out_pos, uint64_t *out_ids,
                                     double *out_scores, uint64_t *out_n);
 
+/* vl_index_search_batch_positions with the queries ALREADY IN DEVICE MEMORY of the index's GPU (e.g. embeddings computed
+ * there, or a batch another rank broadcast with RCCL): d_queries is a device pointer to [nq, q_len] f64, the outputs stay
+ * host buffers ([nq, k] / [nq]; out_pos and out_ids may each be NULL).  Batches the bf16 MFMA filter serves (cosine, dot,
+ * Euclidean; >= 2 queries; an index of >= 8192 rows with dim <= 768) are staged by a kernel -- no host staging, no PCIe copy
+ * of the queries; anything else (Manhattan, one query, a small index, an HNSW handle, queries the filter cannot certify) is
+ * copied to the host and answered exactly as vl_index_search_batch would.  Same results, same errors as the host form.
+ * The caller keeps d_queries valid and unmodified until the call returns (work already queued on other streams that
+ * writes it must have completed). */
+int vl_index_search_batch_dev(const vl_index *h, const double *d_queries, uint64_t nq, uint64_t q_len, uint64_t k,
+                              int metric, uint64_t *out_pos, uint64_t *out_ids, double *out_scores, uint64_t *out_n);
+
 /* ---- row-sharded batched search over RCCL (north_star's config 3; no reference counterpart) ----------
  *
  * One process per GPU.  Rank r holds the contiguous row range [offset_r, offset_r + len_r) of the corpus as an
@@ -257,6 +268,12 @@ int vl_shard_search_batch(const vl_index *shard, vl_comm *comm, const double *qu
                           uint64_t k, int metric, uint64_t *out_gpos, uint64_t *out_ids, double *out_scores,
                           uint64_t *out_n);
 
+/* vl_shard_search_batch with the queries already in this rank's GPU memory (e.g. one rank embedded the batch and
+ * ncclBroadcast it): the local search is vl_index_search_batch_dev.  Every rank of a call uses the same form. */
+int vl_shard_search_batch_dev(const vl_index *shard, vl_comm *comm, const double *d_queries, uint64_t nq, uint64_t q_len,
+                              uint64_t k, int metric, uint64_t *out_gpos, uint64_t *out_ids, double *out_scores,
+                              uint64_t *out_n);
+
 /* The two halves of vl_shard_search_batch for a host that moves the records with its own transport (MPI, gloo,
  * the server's RPC): vl_shard_search_local fills this shard's exchange record (vl_shard_packed_words(nq, ks)
  * u64 words; ks = min(k, longest shard); the local status travels in word 0 and the call itself returns VL_OK
@@ -265,6 +282,9 @@ int vl_shard_search_batch(const vl_index *shard, vl_comm *comm, const double *qu
 uint64_t vl_shard_packed_words(uint64_t nq, uint64_t ks);
 int vl_shard_search_local(const vl_index *shard, uint64_t row_offset, int corpus_has_rows, const double *queries,
                           uint64_t nq, uint64_t q_len, uint64_t ks, int metric, uint64_t *out_packed);
+/* ... the same with device-resident queries (vl_index_search_batch_dev underneath) */
+int vl_shard_search_local_dev(const vl_index *shard, uint64_t row_offset, int corpus_has_rows, const double *d_queries,
+                              uint64_t nq, uint64_t q_len, uint64_t ks, int metric, uint64_t *out_packed);
 int vl_shard_merge(int device, const uint64_t *gathered, uint32_t world, uint64_t nq, uint64_t ks, uint64_t k,
                    uint64_t *out_gpos, uint64_t *out_ids, double *out_scores, uint64_t *out_n);
 

@@ -57,6 +57,8 @@ extern "C" {
     fn vl_comm_destroy(comm: *mut vl_comm);
     fn vl_shard_sync(shard: *const vl_index, comm: *mut vl_comm, out_offset: *mut u64, out_total: *mut u64) -> c_int;
     fn vl_shard_search_batch(shard: *const vl_index, comm: *mut vl_comm, queries: *const f64, nq: u64, q_len: u64, k: u64, metric: c_int, out_gpos: *mut u64, out_ids: *mut u64, out_scores: *mut f64, out_n: *mut u64) -> c_int;
+    fn vl_shard_search_batch_dev(shard: *const vl_index, comm: *mut vl_comm, d_queries: *const f64, nq: u64, q_len: u64, k: u64, metric: c_int, out_gpos: *mut u64, out_ids: *mut u64, out_scores: *mut f64, out_n: *mut u64) -> c_int;
+    fn vl_index_search_batch_dev(h: *const vl_index, d_queries: *const f64, nq: u64, q_len: u64, k: u64, metric: c_int, out_pos: *mut u64, out_ids: *mut u64, out_scores: *mut f64, out_n: *mut u64) -> c_int;
 }
 
 pub const VL_COMM_ID_BYTES: usize = 128;
@@ -232,6 +234,21 @@ impl GpuFlatIndex {
         }
         Ok((0..nq).map(|q| (0..n[q] as usize).map(|i| (ids[q * k + i], scores[q * k + i])).collect()).collect())
     }
+
+    /// `search_batch` for queries that already sit in this GPU's memory (embeddings computed there): `d_queries` is a
+    /// device pointer to `[nq, dim]` f64; no host staging, no PCIe copy of the queries on the MFMA batch path.
+    ///
+    /// # Safety
+    /// `d_queries` must be a valid device allocation of `nq * dim` f64 on the index's GPU, not written until the call returns.
+    pub unsafe fn search_batch_device(&self, d_queries: *const f64, nq: usize, k: usize, metric: SimilarityMetric) -> VectorLiteResult<Vec<Vec<(u64, f64)>>> {
+        let stride = k.min(self.len()).max(1); // min(k, len) results at most; k is clamped to the buffers
+        let (mut ids, mut scores, mut n) = (vec![0u64; nq * stride], vec![0f64; nq * stride], vec![0u64; nq]);
+        let rc = vl_index_search_batch_dev(self.0.raw, d_queries, nq as u64, self.0.dim as u64, k.min(stride) as u64, metric_code(metric), std::ptr::null_mut(), ids.as_mut_ptr(), scores.as_mut_ptr(), n.as_mut_ptr());
+        if rc != VL_OK {
+            return Err(VectorLiteError::InternalError(last_error()));
+        }
+        Ok((0..nq).map(|q| (0..n[q] as usize).map(|i| (ids[q * stride + i], scores[q * stride + i])).collect()).collect())
+    }
 }
 
 impl VectorIndex for GpuFlatIndex {
@@ -333,6 +350,27 @@ impl ShardedGpuFlatIndex {
 
     pub fn shard_mut(&mut self) -> &mut GpuFlatIndex {
         &mut self.shard
+    }
+
+    /// `search_batch` for a batch that already sits in this rank's GPU memory (`d_queries`: device pointer to `[nq, dim]`
+    /// f64 -- e.g. what an `ncclBroadcast` of the batch left there): no host staging, no PCIe copy of the queries.
+    ///
+    /// # Safety
+    /// `d_queries` must be a valid device allocation of `nq * dim` f64 on the shard's GPU, not written until the call returns.
+    pub unsafe fn search_batch_device(&self, d_queries: *const f64, nq: usize, k: usize, metric: SimilarityMetric) -> VectorLiteResult<Vec<Vec<(u64, f64)>>> {
+        let dim = self.shard.0.dim;
+        let stride = k.min(self.total as usize).max(1);
+        let (mut ids, mut scores, mut n) = (vec![0u64; nq * stride], vec![0f64; nq * stride], vec![0u64; nq]);
+        let rc = vl_shard_search_batch_dev(self.shard.0.raw, self.comm, d_queries, nq as u64, dim as u64, k.min(stride) as u64, metric_code(metric), std::ptr::null_mut(), ids.as_mut_ptr(), scores.as_mut_ptr(), n.as_mut_ptr());
+        match rc {
+            VL_OK => Ok((0..nq).map(|q| (0..n[q] as usize).map(|i| (ids[q * stride + i], scores[q * stride + i])).collect()).collect()),
+            VL_ERR_DIM_MISMATCH => {
+                let (mut e, mut a) = (0u64, 0u64);
+                vl_last_dim_mismatch(&mut e, &mut a);
+                Err(VectorLiteError::DimensionMismatch { expected: e as usize, actual: a as usize })
+            }
+            _ => Err(VectorLiteError::InternalError(last_error())),
+        }
     }
 
     /// Collective: nq searches over the whole corpus; identical on every rank; row q is exactly what

@@ -165,6 +165,14 @@ def test_config3_shard_shape_through_vl_shard_search_batch():
         for qi in range(0, nq, 64):
             si, ss = shard.search_arrays(Q[qi], k, V.SimilarityMetric.Euclidean)
             assert si.tolist() == i[qi].tolist() and ss.tolist() == s[qi].tolist()
+        # the same batch already in GPU memory (vl_shard_search_batch_dev; vl_shard_search_local_dev + vl_shard_merge)
+        import torch
+        dQ = torch.from_numpy(Q).to("cuda:0")
+        di, ds, dcnt, dp = sh.search_batch(dQ, k, V.SimilarityMetric.Euclidean, with_positions=True)
+        assert di.tolist() == i.tolist() and ds.tolist() == s.tolist() and dp.tolist() == p.tolist() and dcnt.tolist() == cnt.tolist()
+        sh_t = ShardedFlatIndex(shard, transport="torch")  # world 1 without torch.distributed: the record goes straight to the merge
+        ti, ts, tcnt, tp = sh_t.search_batch(dQ, k, V.SimilarityMetric.Euclidean, with_positions=True)
+        assert ti.tolist() == i.tolist() and ts.tolist() == s.tolist() and tp.tolist() == p.tolist()
         # a mutation without a re-sync is reported, not silently merged
         shard.add(V.Vector(id=10 ** 12, values=rows[0].tolist()))
         with pytest.raises(V.VectorLiteError):

@@ -68,6 +68,18 @@ def main():
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev if world > 1 else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # the same with the batch already in each rank's GPU memory (vl_shard_search_batch_dev: what a broadcast leaves behind)
+    dQ = torch.from_numpy(Q).to(dev)
+    sh.search_batch(dQ, a.k, a.metric)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        d_ids, d_scores, d_n = sh.search_batch(dQ, a.k, a.metric)
+    torch.cuda.synchronize()
+    t_dev = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if world > 1 else "cpu")
+    dist.all_reduce(t_dev, op=dist.ReduceOp.MAX)
+    dev_same = bool(d_ids.tolist() == ids.tolist() and d_scores.tolist() == scores.tolist())
     # every rank must hold the same merged answer: compare a digest
     dig = torch.tensor([int(np.bitwise_xor.reduce(ids.reshape(-1).view(np.int64))),
                         int(np.bitwise_xor.reduce(np.ascontiguousarray(scores).reshape(-1).view(np.int64)))], dtype=torch.int64,
@@ -89,6 +101,9 @@ def main():
                           "roofline": {"bound": "mfma", "achieved": round(flops * a.steps / dt / 1e12 / world, 1), "peak": MFMA_PEAK_TFLOPS,
                                        "unit": "TFLOP/s", "frac": round(flops * a.steps / dt / 1e12 / world / MFMA_PEAK_TFLOPS, 4),
                                        "note": "whole call per GPU (host staging, MFMA filter, f64 rescoring, all-gather, merge), flops = 2*Q*N*dim"},
+                          "device_queries": {"ms_per_batch": round(float(t_dev.item()) / a.steps * 1e3, 3),
+                                             "queries_per_s": round(a.steps * a.batch / float(t_dev.item()), 1),
+                                             "identical_to_host_queries": dev_same},
                           "identical_on_every_rank": same,
                           "own_rows_match_single_search": f"{agree}/{min(a.check, a.batch)}",
                           "config": {"rows": total, "dim": a.dim, "batch": a.batch, "k": a.k, "metric": a.metric,

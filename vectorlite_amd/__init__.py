@@ -300,6 +300,28 @@ class FlatIndex:
                                              _pf64(scores), _pu64(n)))
         return ids[:, :kc], scores[:, :kc], n[:nq]
 
+    def search_batch_device(self, queries, k: int, metric: int = 0, with_positions: bool = False):
+        """search_batch for queries that are already on this index's GPU: `queries` is a contiguous float64 torch tensor
+        [nq, dim] on that device (vl_index_search_batch_dev: no host staging, no PCIe copy of the queries on the MFMA
+        batch path).  Returns (ids, scores, n), or (positions, ids, scores, n) with `with_positions`."""
+        import torch
+        if not isinstance(queries, torch.Tensor) or queries.dtype != torch.float64 or not queries.is_contiguous() \
+                or queries.dim() != 2 or not queries.is_cuda:
+            raise ValueError("queries must be a contiguous float64 [nq, dim] tensor on the index's GPU")
+        nq, qlen = queries.shape
+        kk = max(min(int(k), self.len()), 1)
+        kc = min(int(k), kk)
+        pos = np.zeros((nq, kk), dtype=np.uint64) if with_positions else None
+        ids = np.zeros((nq, kk), dtype=np.uint64)
+        scores = np.zeros((nq, kk), dtype=np.float64)
+        n = np.zeros(max(nq, 1), dtype=np.uint64)
+        torch.cuda.current_stream(queries.device).synchronize()  # whatever produced the queries has finished
+        _raise(self._L.vl_index_search_batch_dev(self._h, C.c_void_p(queries.data_ptr()), nq, qlen, kc, int(metric),
+                                                 _pu64(pos) if with_positions else None, _pu64(ids), _pf64(scores), _pu64(n)))
+        if with_positions:
+            return pos[:, :kc], ids[:, :kc], scores[:, :kc], n[:nq]
+        return ids[:, :kc], scores[:, :kc], n[:nq]
+
     def search_batch_positions(self, queries, k: int, metric: int = 0):
         """(positions, ids, scores, n), each [nq, k] ([nq] for n): the batched search_positions."""
         Q = _f64(queries)

@@ -18,14 +18,14 @@ SYMBOLS = [
     "vl_flat_create", "vl_flat_from_rows", "vl_hnsw_create", "vl_hnsw_create_ex", "vl_index_type", "vl_index_metric", "vl_index_search_ef", "vl_index_clone", "vl_index_destroy", "vl_index_reserve",
     "vl_index_add", "vl_index_add_bulk", "vl_index_add_embeddings_f32", "vl_index_delete", "vl_index_search", "vl_index_search_batch",
     "vl_index_len", "vl_index_is_empty", "vl_index_dimension", "vl_index_get_vector", "vl_index_max_id",
-    "vl_index_export", "vl_index_search_positions", "vl_index_search_batch_positions", "vl_index_hnsw_distances", "vl_hnsw_score",
+    "vl_index_export", "vl_index_search_positions", "vl_index_search_batch_positions", "vl_index_search_batch_dev", "vl_index_hnsw_distances", "vl_hnsw_score",
     "vl_last_error", "vl_last_dim_mismatch", "vl_last_path", "vl_index_force_path", "vl_index_set_single_filter",
     "vl_index_set_coalescing", "vl_index_coalesce_stats", "vl_index_hnsw_walk_stats",
     "vl_vlc_open", "vl_vlc_close", "vl_vlc_name", "vl_vlc_info", "vl_vlc_side_table", "vl_vlc_read_values", "vl_vlc_build_index",
     "vl_index_profile_enable", "vl_index_profile_read", "vl_runtime_info",
     "vl_comm_unique_id", "vl_comm_create", "vl_comm_destroy", "vl_comm_world", "vl_comm_rank",
     "vl_index_hnsw_set_min_beam", "vl_index_hnsw_graph_info", "vl_index_hnsw_graph_export",
-    "vl_shard_sync", "vl_shard_search_batch", "vl_shard_packed_words", "vl_shard_search_local", "vl_shard_merge",
+    "vl_shard_sync", "vl_shard_search_batch", "vl_shard_packed_words", "vl_shard_search_local", "vl_shard_merge", "vl_shard_search_batch_dev", "vl_shard_search_local_dev",
 ]
 
 _lib = None
@@ -80,6 +80,7 @@ def load() -> C.CDLL:
     sig("vl_index_export", i32, [vp, p_u64, p_f64])
     sig("vl_index_search_positions", i32, [vp, p_f64, u64, u64, i32, p_u64, p_u64, p_f64, p_u64])
     sig("vl_index_search_batch_positions", i32, [vp, p_f64, u64, u64, u64, i32, p_u64, p_u64, p_f64, p_u64])
+    sig("vl_index_search_batch_dev", i32, [vp, vp, u64, u64, u64, i32, p_u64, p_u64, p_f64, p_u64])
     sig("vl_index_hnsw_distances", i32, [vp, p_f64, u64, i32, p_u64, u64, p_u64])
     sig("vl_hnsw_score", f64, [u64, i32])
     sig("vl_last_error", C.c_char_p, [])
@@ -114,6 +115,8 @@ def load() -> C.CDLL:
     sig("vl_shard_search_batch", i32, [vp, vp, p_f64, u64, u64, u64, i32, p_u64, p_u64, p_f64, p_u64])
     sig("vl_shard_packed_words", u64, [u64, u64])
     sig("vl_shard_search_local", i32, [vp, u64, i32, p_f64, u64, u64, u64, i32, p_u64])
+    sig("vl_shard_search_batch_dev", i32, [vp, vp, vp, u64, u64, u64, i32, p_u64, p_u64, p_f64, p_u64])
+    sig("vl_shard_search_local_dev", i32, [vp, u64, i32, vp, u64, u64, u64, i32, p_u64])
     sig("vl_shard_merge", i32, [i32, p_u64, C.c_uint32, u64, u64, u64, p_u64, p_u64, p_f64, p_u64])
     _lib = L
     return L

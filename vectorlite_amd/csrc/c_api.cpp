@@ -254,6 +254,30 @@ int vl_index_search_batch_positions(const vl_index* h, const double* queries, ui
     });
 }
 
+int vl_index_search_batch_dev(const vl_index* h, const double* d_queries, uint64_t nq, uint64_t q_len, uint64_t k,
+                              int metric, uint64_t* out_pos, uint64_t* out_ids, double* out_scores, uint64_t* out_n)
+{
+    return guarded([&]() -> int {
+        if (!h || (!out_n && nq)) return VL_ERR_INVALID_ARG;
+        if (h->hnsw) {  // graph walks read their queries from the host staging area: copy, then the usual call
+            if (out_pos) {
+                vl::set_last_error("storage positions are a flat-index notion");
+                return VL_ERR_INVALID_ARG;
+            }
+            std::vector<double> hq;
+            if (d_queries && nq && q_len) {
+                hq.resize((size_t)nq * q_len);
+                if (hipMemcpy(hq.data(), d_queries, hq.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+                    vl::set_last_error("copying the device queries to the host failed");
+                    return VL_ERR_DEVICE;
+                }
+            }
+            return h->hnsw->search_batch(d_queries ? hq.data() : nullptr, nq, q_len, k, metric, 0, out_ids, out_scores, out_n);
+        }
+        return h->flat->search_batch_device(d_queries, nq, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
+    });
+}
+
 // ---- row-sharded batched search over RCCL (shard.hpp) ----------------------------------------------------
 int vl_comm_unique_id(uint8_t* out_id)
 {
@@ -311,6 +335,17 @@ int vl_shard_search_batch(const vl_index* shard, vl_comm* comm, const double* qu
     });
 }
 
+int vl_shard_search_batch_dev(const vl_index* shard, vl_comm* comm, const double* d_queries, uint64_t nq, uint64_t q_len,
+                              uint64_t k, int metric, uint64_t* out_gpos, uint64_t* out_ids, double* out_scores,
+                              uint64_t* out_n)
+{
+    return guarded([&]() -> int {
+        VL_FLAT_ONLY(shard);
+        if (!comm || !comm->c) return VL_ERR_INVALID_ARG;
+        return comm->c->search_batch(shard->flat, d_queries, nq, q_len, k, metric, out_gpos, out_ids, out_scores, out_n, true);
+    });
+}
+
 uint64_t vl_shard_packed_words(uint64_t nq, uint64_t ks) { return vl::shard_packed_words(nq, ks); }
 
 int vl_shard_search_local(const vl_index* shard, uint64_t row_offset, int corpus_has_rows, const double* queries,
@@ -321,6 +356,18 @@ int vl_shard_search_local(const vl_index* shard, uint64_t row_offset, int corpus
         if (!out_packed || metric < 0 || metric > 3) return VL_ERR_INVALID_ARG;
         vl::shard_search_local(shard->flat, row_offset, UINT64_MAX, corpus_has_rows != 0, queries, nq, q_len, ks, metric,
                                reinterpret_cast<unsigned long long*>(out_packed));
+        return VL_OK;  // the search's own status is word 0 of the record
+    });
+}
+
+int vl_shard_search_local_dev(const vl_index* shard, uint64_t row_offset, int corpus_has_rows, const double* d_queries,
+                              uint64_t nq, uint64_t q_len, uint64_t ks, int metric, uint64_t* out_packed)
+{
+    return guarded([&]() -> int {
+        VL_FLAT_ONLY(shard);
+        if (!out_packed || metric < 0 || metric > 3) return VL_ERR_INVALID_ARG;
+        vl::shard_search_local(shard->flat, row_offset, UINT64_MAX, corpus_has_rows != 0, d_queries, nq, q_len, ks, metric,
+                               reinterpret_cast<unsigned long long*>(out_packed), true);
         return VL_OK;  // the search's own status is word 0 of the record
     });
 }

@@ -84,7 +84,7 @@ Workspace::~Workspace()
                    d_opos, d_out_pos, d_out_scores, d_positions, d_dists};
     for (void* p : dev)
         if (p) (void)hipFree(p);
-    void* host[] = {h_q64, h_result, h_nan, mf_h_q64, mf_h_result};
+    void* host[] = {h_q64, h_result, h_nan, mf_h_q64, mf_h_result, mf_h_dom};
     for (void* p : host)
         if (p) (void)hipHostFree(p);
     void* mfd[] = {mf.q_bf16, mf.gmax, mf.thr, mf.cand, mf.cnt, mf_d_q64, mf_lists};
@@ -621,6 +621,13 @@ int GpuFlatIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_le
         return ERR_INVALID_ARG;
     }
     std::shared_lock<std::shared_mutex> lk(mu_);
+    return search_batch_locked(queries, nq, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
+}
+
+// the caller holds mu_ (shared) and has zeroed out_n
+int GpuFlatIndex::search_batch_locked(const double* queries, uint64_t nq, uint64_t q_len, uint64_t k, int metric,
+                                      uint64_t* out_pos, uint64_t* out_ids, double* out_scores, uint64_t* out_n) const
+{
     const uint64_t n = ids_.size();
     if (n != 0 && q_len != dim_) {
         set_dim_mismatch(dim_, q_len);
@@ -665,7 +672,7 @@ int GpuFlatIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_le
     const char* mf_min = getenv("VL_MFMA_MIN_BATCH");
     const uint64_t mfma_min = mf_min && *mf_min ? (uint64_t)atoi(mf_min) : (uint64_t)MFMA_MIN_BATCH;
     if (mfma_on && nq >= mfma_min && n >= MFMA_MIN_ROWS && mfma_scan_supported((uint32_t)dim_, metric)) {
-        VL_TRY(search_batch_mfma(ws, queries, nq, k, k_eff, metric, out_pos, out_ids, out_scores, out_n, &done));
+        VL_TRY(search_batch_mfma(ws, queries, nullptr, nq, k, k_eff, metric, out_pos, out_ids, out_scores, out_n, &done));
         uint64_t left = 0;
         for (uint64_t qi = 0; qi < nq; ++qi) left += done[qi] ? 0 : 1;
         if (left == 0) {
@@ -1060,6 +1067,7 @@ int GpuFlatIndex::ensure_mfma_scratch(Workspace* ws) const
     VL_TRY(pinned_alloc(&ws->mf_h_q64, nqc * (dim_ + 1)));
     VL_TRY(dev_alloc(&ws->mf_lists, nqc * KP));
     VL_TRY(pinned_alloc(&ws->mf_h_result, nqc));
+    VL_TRY(pinned_alloc(&ws->mf_h_dom, nqc));
     ws->mf.nq_cap = (uint32_t)nqc;
     ws->mf.nq_pad_cap = (uint32_t)nqp;
     return OK;
@@ -1067,9 +1075,9 @@ int GpuFlatIndex::ensure_mfma_scratch(Workspace* ws) const
 
 // Cosine / dot / Euclidean batches of >= MFMA_MIN_BATCH queries.  done[qi] is set for every query
 // answered here; the caller redoes the others (bound check failed, candidate overflow, ...).
-int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, uint64_t nq, uint64_t k, uint64_t k_eff,
-                                    int metric, uint64_t* out_pos, uint64_t* out_ids, double* out_scores,
-                                    uint64_t* out_n, std::vector<uint8_t>* done) const
+int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, const double* d_queries, uint64_t nq,
+                                    uint64_t k, uint64_t k_eff, int metric, uint64_t* out_pos, uint64_t* out_ids,
+                                    double* out_scores, uint64_t* out_n, std::vector<uint8_t>* done) const
 {
     const uint64_t n = ids_.size();
     const bool frag = mfma_rows_kernel((uint32_t)dim_);  // which kernel, hence which slab layout
@@ -1089,12 +1097,18 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, uint64
     for (uint64_t q0 = 0; q0 < nq; q0 += seq) {
         const auto t_0 = now();
         const uint32_t g = (uint32_t)std::min<uint64_t>(seq, nq - q0);
-        double* norms = ws->mf_h_q64 + (size_t)g * dim_;
         std::vector<uint8_t> in_domain(g);
-        for (uint32_t j = 0; j < g; ++j)
-            in_domain[j] = stage_query(queries + (q0 + j) * dim_, ws->mf_h_q64 + (size_t)j * dim_, dim_, &norms[j]) ? 1 : 0;
+        if (d_queries) {  // already on this GPU: staged by a kernel; the flags land in pinned memory, read after the sync
+            VL_HIP(launch_stage_queries(st, d_queries + q0 * dim_, g, (uint32_t)dim_, DOMAIN_MAX_ABS, DOMAIN_MIN_NORM,
+                                        ws->mf_d_q64, ws->mf_d_q64 + (size_t)g * dim_, ws->mf_h_dom));
+        } else {
+            double* norms = ws->mf_h_q64 + (size_t)g * dim_;
+            for (uint32_t j = 0; j < g; ++j)
+                in_domain[j] = stage_query(queries + (q0 + j) * dim_, ws->mf_h_q64 + (size_t)j * dim_, dim_, &norms[j]) ? 1 : 0;
+        }
         const auto t_1 = now();
-        VL_HIP(hipMemcpyAsync(ws->mf_d_q64, ws->mf_h_q64, ((size_t)g * dim_ + g) * sizeof(double), hipMemcpyHostToDevice, st));
+        if (!d_queries)
+            VL_HIP(hipMemcpyAsync(ws->mf_d_q64, ws->mf_h_q64, ((size_t)g * dim_ + g) * sizeof(double), hipMemcpyHostToDevice, st));
         if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
         VL_HIP(launch_mfma_candidates(st, metric, slab16, d_norm16_, d_sqnorm_, ws->mf_d_q64, g, n, (uint32_t)dim_,
                                       ws->mf, ws->mf_lists));
@@ -1104,6 +1118,8 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, uint64
                                      ws->mf_h_result, in_extra));
         const auto t_2 = now();
         VL_HIP(hipStreamSynchronize(st));
+        if (d_queries)
+            for (uint32_t j = 0; j < g; ++j) in_domain[j] = ws->mf_h_dom[j];
         const auto t_3 = now();
         if (prof) {
             float ms = 0.f;
@@ -1146,6 +1162,95 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, uint64
             out_n[qi] = k_eff;
             (*done)[qi] = 1;
         }
+    }
+    return OK;
+}
+
+// Queries in device memory.  The MFMA batch path takes them where they are; everything else goes through the host.
+int GpuFlatIndex::search_batch_device(const double* d_queries, uint64_t nq, uint64_t q_len, uint64_t k, int metric,
+                                      uint64_t* out_pos, uint64_t* out_ids, double* out_scores, uint64_t* out_n) const
+{
+    if (nq == 0) return OK;
+    if (!out_n) return ERR_INVALID_ARG;
+    for (uint64_t i = 0; i < nq; ++i) out_n[i] = 0;
+    if (metric < 0 || metric > 3) {
+        set_last_error("unknown metric");
+        return ERR_INVALID_ARG;
+    }
+    VL_HIP(hipSetDevice(device_));
+    auto via_host = [&]() -> int {  // the reference's surface with host queries: every check and path of search_batch()
+        std::vector<double> h;
+        if (d_queries && q_len) {
+            try {
+                h.resize((size_t)nq * q_len);
+            } catch (const std::bad_alloc&) {
+                set_last_error("out of host memory copying the queries");
+                return ERR_OOM;
+            }
+            VL_HIP(hipMemcpy(h.data(), d_queries, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        return search_batch(d_queries ? h.data() : nullptr, nq, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
+    };
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    const uint64_t n = ids_.size();
+    const uint64_t k_eff = std::min<uint64_t>(k, n);
+    const char* mf_env = getenv("VL_MFMA");
+    const char* mf_min = getenv("VL_MFMA_MIN_BATCH");
+    const uint64_t mfma_min = mf_min && *mf_min ? (uint64_t)atoi(mf_min) : (uint64_t)MFMA_MIN_BATCH;
+    const bool direct = d_queries && out_scores && n != 0 && k != 0 && q_len == dim_ && nq > 1 && force_path_.load() == 0 &&
+                        k_eff <= (uint64_t)KFAST_MAX && n_out_of_domain_ == 0 && !(mf_env && mf_env[0] == '0') &&
+                        nq >= mfma_min && n >= MFMA_MIN_ROWS && mfma_scan_supported((uint32_t)dim_, metric);
+    if (!direct) {
+        lk.unlock();
+        return via_host();
+    }
+    std::vector<uint8_t> done(nq, 0);
+    {
+        Workspace* ws = acquire_ws();
+        if (!ws) return ERR_DEVICE;
+        struct Releaser {
+            const GpuFlatIndex* self;
+            Workspace* ws;
+            ~Releaser()
+            {
+                (void)hipStreamSynchronize(ws->stream);
+                self->release_ws(ws);
+            }
+        } rel{this, ws};
+        VL_TRY(search_batch_mfma(ws, nullptr, d_queries, nq, k, k_eff, metric, out_pos, out_ids, out_scores, out_n, &done));
+    }
+    set_last_path(PATH_FAST);
+    // what the filter could not certify (ties, candidate overflow, a query outside the fast-path domain): those queries
+    // go to the host and through search_batch(), results scattered back
+    std::vector<uint64_t> left;
+    for (uint64_t qi = 0; qi < nq; ++qi)
+        if (!done[qi]) left.push_back(qi);
+    if (left.empty()) return OK;
+    const uint64_t m = left.size();
+    std::vector<double> hq;
+    std::vector<uint64_t> t_pos, t_ids, t_n;
+    std::vector<double> t_sc;
+    try {
+        hq.resize(m * dim_);
+        t_pos.resize(m * k_eff);
+        t_ids.resize(m * k_eff);
+        t_sc.resize(m * k_eff);
+        t_n.resize(m);
+    } catch (const std::bad_alloc&) {
+        set_last_error("out of host memory answering the queries the MFMA filter could not certify");
+        return ERR_OOM;
+    }
+    for (uint64_t i = 0; i < m; ++i)
+        VL_HIP(hipMemcpy(hq.data() + i * dim_, d_queries + left[i] * dim_, dim_ * sizeof(double), hipMemcpyDeviceToHost));
+    VL_TRY(search_batch_locked(hq.data(), m, dim_, k_eff, metric, t_pos.data(), t_ids.data(), t_sc.data(), t_n.data()));  // still under the caller's shared lock: one index state for the whole batch
+    for (uint64_t i = 0; i < m; ++i) {
+        const uint64_t qi = left[i];
+        for (uint64_t j = 0; j < t_n[i]; ++j) {
+            if (out_pos) out_pos[qi * k + j] = t_pos[i * k_eff + j];
+            if (out_ids) out_ids[qi * k + j] = t_ids[i * k_eff + j];
+            out_scores[qi * k + j] = t_sc[i * k_eff + j];
+        }
+        out_n[qi] = t_n[i];
     }
     return OK;
 }

@@ -81,6 +81,7 @@ struct Workspace {
     double* mf_h_q64 = nullptr;             // pinned
     Cand32* mf_lists = nullptr;             // [MFMA_MAX_BATCH, KP]
     SearchResultBlock* mf_h_result = nullptr;  // pinned [MFMA_MAX_BATCH]
+    unsigned char* mf_h_dom = nullptr;      // pinned [MFMA_MAX_BATCH]: in-domain flags of device-resident queries
 
     ~Workspace();
 };
@@ -115,6 +116,11 @@ public:
     // [nq, k] with row stride k.
     int search_batch(const double* queries, uint64_t nq, uint64_t q_len, uint64_t k, int metric, uint64_t* out_pos,
                      uint64_t* out_ids, double* out_scores, uint64_t* out_n) const;
+    // NEW: search_batch with the queries already in device memory of this index's GPU (embeddings computed there): the
+    // MFMA batch path stages them with a kernel -- no host staging, no PCIe copy of the queries; whatever that path does
+    // not serve (Manhattan, one query, small indexes, queries it cannot certify) is copied to the host and answered there.
+    int search_batch_device(const double* d_queries, uint64_t nq, uint64_t q_len, uint64_t k, int metric, uint64_t* out_pos,
+                            uint64_t* out_ids, double* out_scores, uint64_t* out_n) const;
     uint64_t len() const;
     bool is_empty() const { return len() == 0; }
     uint64_t dimension() const { return dim_; }
@@ -170,9 +176,11 @@ private:
                   std::vector<double>* scores) const;
     int ensure_bf16_slab(bool frag_major) const;  // lazily builds the bf16 slab (row-major, or MFMA fragment order) a filter streams
     int ensure_mfma_scratch(Workspace* ws) const;
-    int search_batch_mfma(Workspace* ws, const double* queries, uint64_t nq, uint64_t k, uint64_t k_eff, int metric,
-                          uint64_t* out_pos, uint64_t* out_ids, double* out_scores, uint64_t* out_n,
-                          std::vector<uint8_t>* done) const;
+    int search_batch_locked(const double* queries, uint64_t nq, uint64_t q_len, uint64_t k, int metric, uint64_t* out_pos,
+                            uint64_t* out_ids, double* out_scores, uint64_t* out_n) const;  // mu_ held (shared)
+    int search_batch_mfma(Workspace* ws, const double* queries, const double* d_queries, uint64_t nq, uint64_t k,
+                          uint64_t k_eff, int metric, uint64_t* out_pos, uint64_t* out_ids, double* out_scores,
+                          uint64_t* out_n, std::vector<uint8_t>* done) const;  // queries on the host, or d_queries on the device
 
     const uint64_t dim_;
     const uint32_t ld_;  // slab row stride in floats: dim rounded up to 4 (16-byte vector loads)

@@ -1142,6 +1142,40 @@ __global__ void k_queries_bf16(const double* __restrict__ q64, uint32_t nq, uint
     }
 }
 
+// Queries that are already in device memory: what stage_query() (flat_index.cpp) does on the host -- copy into the
+// staging area, norm, and the fast-path domain test (finite, |v| <= max_abs, norm 0 or >= min_norm; a query outside it is
+// staged as zeros with norm 0 and its flag cleared: the caller answers it on the exact path).  One wave per query.
+// The norm only feeds the error bound and that test (the kernels recompute every score from the values).
+__global__ __launch_bounds__(256) void k_stage_queries(const double* __restrict__ src, uint32_t nq, uint32_t dim,
+                                                       double max_abs, double min_norm, double* __restrict__ dst,
+                                                       double* __restrict__ norms, unsigned char* __restrict__ in_domain)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    const double* q = src + (size_t)qi * dim;
+    double ss = 0.0, mx = 0.0;
+    for (uint32_t c = lane; c < dim; c += 64) {
+        const double v = q[c];
+        ss += v * v;
+        const double av = fabs(v);
+        mx = av > mx ? av : mx;  // ignores NaN (ss carries it)
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        ss += __shfl_xor(ss, off);
+        const double o = __shfl_xor(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    const double norm = sqrt(ss);
+    const bool finite = ss == ss && mx <= 1.797693134862315708e308 && norm <= 1.797693134862315708e308;
+    const bool ok = finite && mx <= max_abs && (norm == 0.0 || norm >= min_norm);
+    for (uint32_t c = lane; c < dim; c += 64) dst[(size_t)qi * dim + c] = ok ? q[c] : 0.0;
+    if (lane == 0) {
+        norms[qi] = ok ? norm : 0.0;
+        in_domain[qi] = ok ? 1 : 0;
+    }
+}
+
 // f64 master rows -> UNIT-NORMALISED bf16 slab rows [n, ldb] (x/|x| in f64, then f32, then bf16 RNE;
 // zero rows stay zero), plus |row| and |row|^2 rounded once to f32.  One wave per row.
 __global__ __launch_bounds__(256) void k_rows_bf16(const double* __restrict__ master, uint64_t n, uint32_t dim,
@@ -1263,6 +1297,15 @@ hipError_t launch_rows_bf16(hipStream_t s, const double* master, uint64_t n, uin
     return hipGetLastError();
 }
 
+hipError_t launch_stage_queries(hipStream_t s, const double* d_src, uint32_t nq, uint32_t dim, double max_abs,
+                                double min_norm, double* d_dst, double* d_norms, unsigned char* in_domain)
+{
+    if (nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_stage_queries, dim3((nq + 3) / 4), dim3(256), 0, s, d_src, nq, dim, max_abs, min_norm, d_dst, d_norms,
+                       in_domain);
+    return hipGetLastError();
+}
+
 uint32_t mfma_sequence_queries(uint32_t dim)
 {
     if (!mfma_rows_kernel(dim)) return 1024;  // the LDS-tile kernel: 4 chunks of 256
@@ -1368,7 +1411,9 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
             // looser thresholds only add a few hundred candidates per query to the first stage
             const uint32_t sample_div = sd && *sd && atoi(sd) > 0 ? (uint32_t)atoi(sd) : (n_blocks >= 131072u ? 64u : 32u);
             uint32_t sample_blocks = n_blocks / sample_div;
-            const uint32_t min_blocks = std::min<uint32_t>(n_blocks, 65536u / 32u);
+            const char* sm = getenv("VL_MFMA_SAMPLE_MIN");  // rows
+            const uint32_t min_rows = sm && *sm && atoi(sm) >= 2048 ? (uint32_t)atoi(sm) : 65536u;
+            const uint32_t min_blocks = std::min<uint32_t>(n_blocks, min_rows / 32u);
             if (sample_blocks < min_blocks) sample_blocks = min_blocks;
             const uint64_t r_sample_rows = std::min<uint64_t>((uint64_t)sample_blocks * 32, n_rows);
             const uint32_t wg_cap = (uint32_t)env_grid(r_chunks);  // co-resident workgroups per query chunk

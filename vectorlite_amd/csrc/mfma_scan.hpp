@@ -52,6 +52,10 @@ bool mfma_scan_supported(uint32_t dim, int metric);
 // at least 128 groups, i.e. 16 workgroups of 8 waves per query chunk -- at most 16 co-resident chunks on 256 CUs:
 // 16 x 128 queries up to stride 512, 16 x 64 at stride 768.
 uint32_t mfma_sequence_queries(uint32_t dim);
+// Queries already in device memory -> the staging area of a launch sequence: d_dst [nq, dim] (zeros for a query outside
+// the fast-path domain), d_norms [nq], in_domain [nq] (device-visible, e.g. pinned host memory).
+hipError_t launch_stage_queries(hipStream_t s, const double* d_src, uint32_t nq, uint32_t dim, double max_abs,
+                                double min_norm, double* d_dst, double* d_norms, unsigned char* in_domain);
 
 // f64 master rows [n, dim] -> UNIT-NORMALISED bf16 rows [n, ldb] (x/|x| in f64 -> f32 -> bf16, round to
 // nearest even), |row| and |row|^2 (f64, rounded once to f32)

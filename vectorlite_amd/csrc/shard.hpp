@@ -45,7 +45,7 @@ hipError_t launch_shard_merge(hipStream_t stream, const unsigned long long* gath
 // non-empty index still rejects a query of the wrong length, like one index holding all rows would).
 void shard_search_local(const GpuFlatIndex* shard, uint64_t row_offset, uint64_t expected_len, bool any_rows,
                         const double* queries, uint64_t nq, uint64_t q_len, uint64_t ks, int metric,
-                        unsigned long long* packed);
+                        unsigned long long* packed, bool queries_on_device = false);  // queries: host, or this GPU's memory
 
 // Device buffers + stream for gather/merge on one GPU.
 class ShardMerger {
@@ -89,7 +89,8 @@ public:
     int sync(const GpuFlatIndex* shard, uint64_t* out_offset, uint64_t* out_total);
     // collective: local search + ONE all-gather + device merge; outputs [nq, k] (row stride k), identical on every rank
     int search_batch(const GpuFlatIndex* shard, const double* queries, uint64_t nq, uint64_t q_len, uint64_t k, int metric,
-                     uint64_t* out_gpos, uint64_t* out_ids, double* out_scores, uint64_t* out_n);
+                     uint64_t* out_gpos, uint64_t* out_ids, double* out_scores, uint64_t* out_n,
+                     bool queries_on_device = false);
 
 private:
     ShardComm(int world, int rank, int device) : world_(world), rank_(rank), merger_(device) {}

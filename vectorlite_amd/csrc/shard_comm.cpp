@@ -38,7 +38,7 @@ static_assert(sizeof(unsigned long long) == sizeof(uint64_t) && sizeof(double) =
 // ---------------------------------------------------------------------------------------------------------
 void shard_search_local(const GpuFlatIndex* shard, uint64_t row_offset, uint64_t expected_len, bool any_rows,
                         const double* queries, uint64_t nq, uint64_t q_len, uint64_t ks, int metric,
-                        unsigned long long* packed)
+                        unsigned long long* packed, bool queries_on_device)
 {
     const uint64_t words = shard_packed_words(nq, ks), plane = nq * ks;
     std::memset(packed, 0, words * sizeof(unsigned long long));
@@ -63,9 +63,13 @@ void shard_search_local(const GpuFlatIndex* shard, uint64_t row_offset, uint64_t
         unsigned long long* gp = sc + plane;
         unsigned long long* id = gp + plane;
         try {
-            status = shard->search_batch(queries, nq, q_len, ks, metric, reinterpret_cast<uint64_t*>(gp),
-                                         reinterpret_cast<uint64_t*>(id), reinterpret_cast<double*>(sc),
-                                         reinterpret_cast<uint64_t*>(cnt));
+            status = queries_on_device
+                         ? shard->search_batch_device(queries, nq, q_len, ks, metric, reinterpret_cast<uint64_t*>(gp),
+                                                      reinterpret_cast<uint64_t*>(id), reinterpret_cast<double*>(sc),
+                                                      reinterpret_cast<uint64_t*>(cnt))
+                         : shard->search_batch(queries, nq, q_len, ks, metric, reinterpret_cast<uint64_t*>(gp),
+                                               reinterpret_cast<uint64_t*>(id), reinterpret_cast<double*>(sc),
+                                               reinterpret_cast<uint64_t*>(cnt));
         } catch (const std::bad_alloc&) {
             status = ERR_OOM;
             set_last_error("host allocation failed in the shard search");
@@ -270,7 +274,8 @@ int ShardComm::sync(const GpuFlatIndex* shard, uint64_t* out_offset, uint64_t* o
 }
 
 int ShardComm::search_batch(const GpuFlatIndex* shard, const double* queries, uint64_t nq, uint64_t q_len, uint64_t k,
-                            int metric, uint64_t* out_gpos, uint64_t* out_ids, double* out_scores, uint64_t* out_n)
+                            int metric, uint64_t* out_gpos, uint64_t* out_ids, double* out_scores, uint64_t* out_n,
+                            bool queries_on_device)
 {
     if (nq == 0) return OK;
     if (!out_n) return ERR_INVALID_ARG;
@@ -297,7 +302,8 @@ int ShardComm::search_batch(const GpuFlatIndex* shard, const double* queries, ui
     }
     int rc = merger_.ensure((uint64_t)world_, nq, ks, k_out);
     if (rc != OK) return rc;
-    shard_search_local(shard, offset_, lens_[(size_t)rank_], total_ != 0, queries, nq, q_len, ks, metric, merger_.h_send());
+    shard_search_local(shard, offset_, lens_[(size_t)rank_], total_ != 0, queries, nq, q_len, ks, metric, merger_.h_send(),
+                       queries_on_device);
     const std::string local_msg = merger_.h_send()[0] != 0 ? std::string(last_error()) : std::string();
     SH_HIP(hipSetDevice(merger_.device()));
     SH_HIP(hipMemcpyAsync(merger_.d_send(), merger_.h_send(), words * 8, hipMemcpyHostToDevice, merger_.stream()));

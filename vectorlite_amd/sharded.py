@@ -44,6 +44,14 @@ def shard_ranges(n_rows: int, world: int):
     return starts
 
 
+def _is_device_tensor(x) -> bool:
+    try:
+        import torch
+    except Exception:  # pragma: no cover
+        return False
+    return isinstance(x, torch.Tensor) and x.is_cuda
+
+
 def pack_words(nq: int, ks: int) -> int:
     """vl_shard_packed_words: u64 words of one rank's exchange record."""
     return SHARD_HDR_WORDS + nq + 3 * nq * ks
@@ -182,9 +190,17 @@ class ShardedFlatIndex:
         """nq independent searches over the whole (sharded) corpus.
         Returns (ids [nq, k], scores [nq, k], n [nq]) -- identical on every rank (+ gpos [nq, k] on request)."""
         from . import _raise
-        Q = np.ascontiguousarray(np.asarray(queries, dtype=np.float64))
-        if Q.ndim == 1:
-            Q = Q[None, :]
+        on_device = _is_device_tensor(queries)  # a contiguous float64 [nq, dim] torch tensor on this shard's GPU: no host staging
+        if on_device:
+            import torch
+            if queries.dtype != torch.float64 or not queries.is_contiguous() or queries.dim() != 2:
+                raise ValueError("device queries must be a contiguous float64 [nq, dim] tensor")
+            torch.cuda.current_stream(queries.device).synchronize()  # whatever produced them has finished
+            Q, qptr = queries, C.c_void_p(queries.data_ptr())
+        else:
+            Q = np.ascontiguousarray(np.asarray(queries, dtype=np.float64))
+            if Q.ndim == 1:
+                Q = Q[None, :]
         nq, qlen = Q.shape
         k = int(k)
         kk = max(min(k, max(self.total, 1)), 1)  # output row stride: min(k, total rows) results at most
@@ -194,11 +210,20 @@ class ShardedFlatIndex:
         n = np.zeros(max(nq, 1), dtype=np.uint64)
         k_call = min(k, kk)  # results for a smaller k are a prefix: the buffers can never be overrun
         if self.transport == "rccl":
-            _raise(self._L.vl_shard_search_batch(self.local._h, self.comm._h, _pf64(Q), nq, qlen, k_call, int(metric),
-                                                 _pu64(gpos), _pu64(ids), _pf64(scores), _pu64(n)))
+            if on_device:
+                _raise(self._L.vl_shard_search_batch_dev(self.local._h, self.comm._h, qptr, nq, qlen, k_call, int(metric),
+                                                         _pu64(gpos), _pu64(ids), _pf64(scores), _pu64(n)))
+            else:
+                _raise(self._L.vl_shard_search_batch(self.local._h, self.comm._h, _pf64(Q), nq, qlen, k_call, int(metric),
+                                                     _pu64(gpos), _pu64(ids), _pf64(scores), _pu64(n)))
         elif k_call > 0 and self.total > 0 and nq > 0:
             ks = min(k_call, self.max_len)
-            rec = self._local_record(Q, ks, int(metric))
+            if on_device:
+                rec = np.zeros(pack_words(nq, ks), dtype=np.uint64)
+                _raise(self._L.vl_shard_search_local_dev(self.local._h, self.offset, 1 if self.total else 0, qptr, nq, qlen,
+                                                         ks, int(metric), _pu64(rec)))
+            else:
+                rec = self._local_record(Q, ks, int(metric))
             gathered = np.ascontiguousarray(self._torch_all_gather(rec))
             self._merge(gathered, nq, ks, k_call, gpos, ids, scores, n)
         out = (ids[:, :k_call], scores[:, :k_call], n[:nq])
