@@ -27,6 +27,10 @@ while time.time() < t_end:
     for i in (0, 7, 39):
         one = idx.search_arrays(Q[i], 10, 0)
         assert b[0][i].tolist() == one[0].tolist() and b[1][i].tolist() == one[1].tolist()
+    dq = torch.from_numpy(np.ascontiguousarray(Q)).to("cuda:0")  # the same batch from device memory
+    bd = idx.search_batch_device(dq, 10, 0); searches += 40
+    assert bd[0].tolist() == b[0].tolist() and bd[1].tolist() == b[1].tolist()
+    del dq
     idx.set_single_filter("bf16"); idx.search_arrays(Q[1], 10, 0); idx.set_single_filter("f32")
     idx.search_arrays(Q[2], 100, 1); idx.search_arrays(Q[2], 700, 1)
     idx.set_coalescing(32, 100)
