@@ -56,7 +56,11 @@ while time.time() < t_end:
     if mode == "bf16":
         gpu.set_single_filter("bf16")
     if mode == "batch":
-        bi, bs, bn = gpu.search_batch(Q, k, m)
+        if rng.integers(0, 2):  # half of the batches come from device memory (vl_index_search_batch_dev)
+            import torch
+            bi, bs, bn = gpu.search_batch_device(torch.from_numpy(np.ascontiguousarray(Q)).to('cuda:0'), k, m)
+        else:
+            bi, bs, bn = gpu.search_batch(Q, k, m)
         got = [(bi[i, : bn[i]], bs[i, : bn[i]]) for i in range(nq)]
     elif mode == "positions":
         got = []

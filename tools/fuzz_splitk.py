@@ -44,7 +44,11 @@ while time.time() < t_end:
     m = int(rng.choice([0, 1, 3]))
     k = int(rng.choice([1, 10, 48, 60]))
     gpu.profile_read(); gpu.profile_enable(True)
-    bi, bs, bn = gpu.search_batch(Q, k, m)
+    if rng.integers(0, 2):  # half of the batches come from device memory (vl_index_search_batch_dev)
+        import torch
+        bi, bs, bn = gpu.search_batch_device(torch.from_numpy(np.ascontiguousarray(Q)).to('cuda:0'), k, m)
+    else:
+        bi, bs, bn = gpu.search_batch(Q, k, m)
     gpu.profile_enable(False)
     mfma_passes += 1 if gpu.profile_read()[0] < nq else 0   # fewer passes than queries: the batch filter served it
     for i in range(nq):
