@@ -1031,3 +1031,33 @@ def test_coalesced_searches_with_a_huge_k_do_not_wedge_the_queue(V, O):
             assert gi.tolist() == want[t][0].tolist() and gs.tolist() == want[t][1].tolist(), (k, t)
     gi, gs = gpu.search_arrays(Q[0], 10, 0)  # and an ordinary search afterwards
     assert gi.tolist() == want[0][0][:10].tolist()
+
+
+@pytest.mark.parametrize("dim,metric,nq", [(384, "cosine", 640), (384, "dotproduct", 1408), (768, "euclidean", 1024),
+                                            (768, "cosine", 480), (200, "euclidean", 896)])
+def test_mfma_batches_whose_chunk_count_8_does_not_divide(V, O, dim, metric, nq):
+    """5 / 11 chunks of 128 queries, 11 / 5 chunks of 96 at stride 768, 7 chunks at stride 256: the grids (51, 23, 36 ...
+    row-block lanes per chunk) on which the XCD-aware workgroup map (csrc/xcd_map.hpp) is not the identity.  Every row
+    block must still be worked on exactly once per chunk: each batch row equals the single-query pipeline, a sample the oracle."""
+    rng = np.random.default_rng(dim + nq)
+    n = 150_000
+    rows = unit_rows(rng, n, dim) * (1.0 + rng.random((n, 1)))
+    ids = permuted_ids(n)
+    idx = V.FlatIndex(dim)
+    idx.add_rows(ids, rows, validate=False)
+    Q = unit_rows(rng, nq, dim)
+    idx.profile_read()
+    idx.profile_enable(True)
+    bi, bs, bn = idx.search_batch(Q, 10, M[metric])
+    idx.profile_enable(False)
+    n_seq, _, _ = idx.profile_read()
+    # the MFMA filter's launch sequences served it (a few queries it cannot certify are redone one by one: the GEMM-form
+    # Euclidean bound is loose when the row norms vary), not one f32 pass per 8 queries
+    assert 1 <= n_seq <= 2 + nq // 20
+    assert bn.tolist() == [10] * nq
+    for qi in list(range(0, nq, 37)) + [nq - 1]:
+        si, ss = idx.search_arrays(Q[qi], 10, M[metric])
+        assert bi[qi].tolist() == si.tolist() and bs[qi].tolist() == ss.tolist(), (qi, V.last_path())
+    ref = O.FlatOracle(dim, ids, rows)
+    for qi in (0, nq // 2, nq - 1):
+        assert_same(V, (bi[qi], bs[qi]), ref.search(Q[qi], 10, M[metric]), (dim, metric, nq, qi))
