@@ -679,7 +679,7 @@ int GpuFlatIndex::search_batch_locked(const double* queries, uint64_t nq, uint64
             set_last_path(PATH_FAST);
             return OK;
         }
-        if (left < nq || !f32_batch) {  // few stragglers: answer them one by one on the f32 path
+        if (left <= 2 || !f32_batch) {  // one or two stragglers (or no 8-query f32 shape): one by one on the f32 path
             for (uint64_t qi = 0; qi < nq; ++qi)
                 if (!done[qi]) VL_TRY(single(qi, false));
             return OK;
@@ -690,13 +690,19 @@ int GpuFlatIndex::search_batch_locked(const double* queries, uint64_t nq, uint64
         return OK;
     }
 
+    // what is left (everything, or what the MFMA filter could not certify): 8 queries per f32 slab pass
+    std::vector<uint64_t> todo;
+    todo.reserve(nq);
+    for (uint64_t qi = 0; qi < nq; ++qi)
+        if (!done[qi]) todo.push_back(qi);
+    const uint64_t nt = todo.size();
     const bool prof = profile_.load();
-    for (uint64_t q0 = 0; q0 < nq; q0 += SCAN_BATCH_QB) {
-        const uint32_t g = (uint32_t)std::min<uint64_t>(SCAN_BATCH_QB, nq - q0);
+    for (uint64_t q0 = 0; q0 < nt; q0 += SCAN_BATCH_QB) {
+        const uint32_t g = (uint32_t)std::min<uint64_t>(SCAN_BATCH_QB, nt - q0);
         bool in_domain[SCAN_BATCH_QB];
         double* norms = ws->h_q64 + (size_t)g * dim_;
         for (uint32_t j = 0; j < g; ++j)
-            in_domain[j] = stage_query(queries + (q0 + j) * dim_, ws->h_q64 + (size_t)j * dim_, dim_, &norms[j]);
+            in_domain[j] = stage_query(queries + todo[q0 + j] * dim_, ws->h_q64 + (size_t)j * dim_, dim_, &norms[j]);
         VL_HIP(hipMemcpyAsync(ws->d_q64, ws->h_q64, ((size_t)g * dim_ + g) * sizeof(double), hipMemcpyHostToDevice, st));
         ScanPlan plan;
         if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
@@ -719,7 +725,7 @@ int GpuFlatIndex::search_batch_locked(const double* queries, uint64_t nq, uint64
         SearchResultBlock blocks[SCAN_BATCH_QB];
         std::memcpy(blocks, ws->h_result, g * sizeof(SearchResultBlock));
         for (uint32_t j = 0; j < g; ++j) {
-            const uint64_t qi = q0 + j;
+            const uint64_t qi = todo[q0 + j];
             const SearchResultBlock& r = blocks[j];
             bool ok = in_domain[j] && !(r.flags & RESULT_NEEDS_EXACT) && r.n_out == k_eff;
             if (ok) {
