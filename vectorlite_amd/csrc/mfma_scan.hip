@@ -17,6 +17,7 @@
 //     with the bf16 input-rounding term (2^-8 relative per operand) in the bound.
 // A query whose check fails (or whose buffer overflows) is redone on the f32 path by the host.
 #include "mfma_scan.hpp"
+#include "filter_plan.hpp"
 #include "xcd_map.hpp"
 
 #include <stdlib.h>
@@ -1404,60 +1405,24 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
             }
             hipError_t e2 = hipMemsetAsync(w.cnt, 0, (size_t)rnq_pad * sizeof(uint32_t), s);
             if (e2 != hipSuccess) return e2;
-            const uint32_t n_blocks = (uint32_t)((n_rows + 31) / 32);
-            // pass 0 over a sample of the blocks (>= 65536 rows or everything): one group per workgroup
-            const char* sd = getenv("VL_MFMA_SAMPLE_DIV");
-            // 1/32 of the blocks; 1/64 on long scans (>= 4 M rows), where the floor of 65536 rows is far away and the
-            // looser thresholds only add a few hundred candidates per query to the first stage
-            const uint32_t sample_div = sd && *sd && atoi(sd) > 0 ? (uint32_t)atoi(sd) : (n_blocks >= 131072u ? 64u : 32u);
-            uint32_t sample_blocks = n_blocks / sample_div;
-            const char* sm = getenv("VL_MFMA_SAMPLE_MIN");  // rows
-            const uint32_t min_rows = sm && *sm && atoi(sm) >= 2048 ? (uint32_t)atoi(sm) : 65536u;
-            const uint32_t min_blocks = std::min<uint32_t>(n_blocks, min_rows / 32u);
-            if (sample_blocks < min_blocks) sample_blocks = min_blocks;
-            const uint64_t r_sample_rows = std::min<uint64_t>((uint64_t)sample_blocks * 32, n_rows);
+            // the launch plan (filter_plan.hpp): sample size and sampling grid, where the pass-1 stages end
             const uint32_t wg_cap = (uint32_t)env_grid(r_chunks);  // co-resident workgroups per query chunk
-            // sampling pass: the grid of pass 1 (every CU busy, one round), each workgroup reporting gpw groups so that
-            // k_thresholds sees up to MFMA_GROUPS of them (>= 64 as soon as the sample holds 64 blocks)
-            uint32_t gx0 = std::max<uint32_t>(1u, std::min<uint32_t>({(sample_blocks + RS_NWAVES - 1) / RS_NWAVES, wg_cap, (uint32_t)MFMA_GROUPS}));
-            // never fewer than 128 groups when the sample has the blocks for them (the 64th largest of 64 group maxima is
-            // the smallest of them: a threshold so loose that every candidate buffer overflows); more workgroups than are
-            // co-resident just queue up
-            if (gx0 * RS_NWAVES < 128u) gx0 = std::max<uint32_t>(gx0, std::min<uint32_t>(16u, (sample_blocks + RS_NWAVES - 1) / RS_NWAVES));
-            uint32_t r_gpw = 1;
-            while (r_gpw < (uint32_t)RS_NWAVES && gx0 * r_gpw * 2 <= (uint32_t)MFMA_GROUPS) r_gpw *= 2;
-            if (sample_blocks < gx0 * r_gpw) {  // tiny sample: one block per group at most
-                r_gpw = RS_NWAVES;
-                gx0 = std::max<uint32_t>(1u, (sample_blocks + RS_NWAVES - 1) / RS_NWAVES);
-            }
-            const uint32_t r_groups = gx0 * r_gpw;
-            // Pass 1 in stages of growing size; between stages every query's threshold is tightened to its 64th best
-            // candidate so far (k_refine_thresholds).  The candidate code is not free (ballots, ring writes: the wave
-            // leaves the MFMA stream for hundreds of cycles), and how often a wave enters it is set by the threshold: with the
-            // sampled one about 64 x (stage rows / sample rows) rows per query pass, after a refine 64 x (stage rows /
-            // rows scanned so far).  So the first stage is short and the stages grow geometrically -- 1/16, 3/16, 7/16 of
-            // the blocks on long scans (>= 4 M rows), where a refine launch (~50 us with its gaps) is noise; a shard of
-            // ~1 M rows (config 3) is fastest with two (measured: 2.015 -> 1.953 ms at 1.25 M x 768, 1024 queries).
-            uint32_t st_end[5] = {0, n_blocks, n_blocks, n_blocks, n_blocks};
-            int r_stages = 1;
-            {
-                const char* se = getenv("VL_MFMA_STAGES");
-                const int want = se && *se ? atoi(se) : (n_blocks >= 131072u ? 4 : 2);
-                if (want >= 2 && n_blocks >= 128u * RS_NWAVES * wg_cap) {
-                    r_stages = want >= 4 ? 4 : want;
-                    static const uint32_t dflt[5][3] = {{0, 0, 0}, {0, 0, 0}, {2, 0, 0}, {3, 7, 0}, {1, 3, 7}};  // sixteenths
-                    static const char* const names[3] = {"VL_MFMA_STAGE1", "VL_MFMA_STAGE2", "VL_MFMA_STAGE3"};
-                    uint32_t prev = 0;
-                    for (int st = 1; st < r_stages; ++st) {
-                        const char* sv = getenv(names[st - 1]);
-                        uint32_t f = sv && *sv ? (uint32_t)atoi(sv) : dflt[r_stages][st - 1];
-                        f = std::min<uint32_t>(std::max<uint32_t>(f, prev), 16u);  // stage ends never go backwards
-                        st_end[st] = (uint32_t)((uint64_t)n_blocks * f / 16);
-                        prev = f;
-                    }
-                    st_end[r_stages] = n_blocks;
-                }
-            }
+            FilterKnobs kn;
+            auto env_u = [](const char* name) -> uint32_t {
+                const char* v = getenv(name);
+                return v && *v && atoi(v) > 0 ? (uint32_t)atoi(v) : 0u;
+            };
+            kn.sample_div = env_u("VL_MFMA_SAMPLE_DIV");
+            kn.sample_min_rows = env_u("VL_MFMA_SAMPLE_MIN");
+            kn.stages = (int)env_u("VL_MFMA_STAGES");
+            kn.stage_end[0] = env_u("VL_MFMA_STAGE1");
+            kn.stage_end[1] = env_u("VL_MFMA_STAGE2");
+            kn.stage_end[2] = env_u("VL_MFMA_STAGE3");
+            const FilterPlan fp = filter_plan(n_rows, wg_cap, (uint32_t)RS_NWAVES, (uint32_t)MFMA_GROUPS, kn);
+            const uint32_t sample_blocks = fp.sample_blocks, gx0 = fp.gx0, r_gpw = fp.gpw, r_groups = fp.groups;
+            const uint64_t r_sample_rows = std::min<uint64_t>((uint64_t)sample_blocks * 32, n_rows);
+            const int r_stages = fp.stages;
+            const uint32_t* st_end = fp.st_end;
             bool r_launched = false;
 #define VL_RLAUNCH2(K, MET)                                                                                                     \
     {                                                                                                                           \
