@@ -2,15 +2,18 @@
 //
 // No reference counterpart (the reference has no batch search, src/lib.rs:224-245).  With hundreds of
 // queries per slab pass the scan stops being HBM-bound, so scores[row, query] are
-// computed on the matrix cores: v_mfma_f32_16x16x32_bf16 (2 x 2 blocks of 16 per wave), rows as the A operand
-// (streamed through LDS, one contiguous 32-row tile at a time), 32 queries per wave as the B operand held in registers
-// for the whole launch (256 queries per 8-wave workgroup share every row tile).
+// computed on the matrix cores (v_mfma_f32_16x16x32_bf16).  Two kernels:
+//   k_mfma_rows (K4r, the shipped one, every row stride 128 .. 768): row-stationary waves -- a workgroup's queries
+//     sit in LDS, every wave streams its own 32-row blocks from the fragment-major slab into A-fragment registers;
+//     workgroups are placed XCD-aware (xcd_map.hpp), the launch plan is filter_plan.hpp;
+//   k_mfma_scan (round 1's LDS-tile kernel, only with VL_MFMA_KERNEL=tile): rows streamed through an LDS tile, 32
+//     queries per wave held in registers.
 //
 // bf16 scores are only a CANDIDATE FILTER.  The Q x N score matrix is never written:
-//   pass 0 (a sample: 1/16 of the rows, at least 65536 of them): every workgroup reports, per query, the best key of its
-//     own set of row tiles; the 64th largest of those maxima is a valid lower bound T_q of the
-//     query's 64th best key (64 distinct rows reach it);
-//   pass 1 (all rows, in three stages of growing size; between stages T_q is raised to the 64th best
+//   pass 0 (a sample: 1/32 .. 1/64 of the rows, at least 65536 of them): every group of row blocks reports, per query,
+//     its best key; the 64th largest of those maxima is a valid lower bound T_q of the query's 64th best key
+//     (64 distinct rows reach it);
+//   pass 1 (all rows, in up to four stages of growing size; between stages T_q is raised to the 64th best
 //     candidate found so far): keys >= T_q are appended to the query's candidate buffer (a few hundred of 10^7);
 //   then per query: top-64 of the buffer -> the same finalize kernel as the f32 path: exact f64
 //     rescoring from the master rows, (score desc, position asc) ranking and the bound check, now
