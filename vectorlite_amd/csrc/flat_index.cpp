@@ -1199,11 +1199,20 @@ int GpuFlatIndex::search_batch_device(const double* d_queries, uint64_t nq, uint
     };
     std::shared_lock<std::shared_mutex> lk(mu_);
     const uint64_t n = ids_.size();
+    // the checks of search_batch(), before any byte of the queries is touched (src/index/flat.rs:99-104: an empty index
+    // accepts any query length)
+    if (n != 0 && q_len != dim_) {
+        set_dim_mismatch(dim_, q_len);
+        set_last_error("Dimension mismatch: expected " + std::to_string(dim_) + ", got " + std::to_string(q_len));
+        return ERR_DIM_MISMATCH;
+    }
+    if (n == 0 || k == 0) return OK;
+    if (!d_queries || !out_scores) return ERR_INVALID_ARG;
     const uint64_t k_eff = std::min<uint64_t>(k, n);
     const char* mf_env = getenv("VL_MFMA");
     const char* mf_min = getenv("VL_MFMA_MIN_BATCH");
     const uint64_t mfma_min = mf_min && *mf_min ? (uint64_t)atoi(mf_min) : (uint64_t)MFMA_MIN_BATCH;
-    const bool direct = d_queries && out_scores && n != 0 && k != 0 && q_len == dim_ && nq > 1 && force_path_.load() == 0 &&
+    const bool direct = nq > 1 && force_path_.load() == 0 &&
                         k_eff <= (uint64_t)KFAST_MAX && n_out_of_domain_ == 0 && !(mf_env && mf_env[0] == '0') &&
                         nq >= mfma_min && n >= MFMA_MIN_ROWS && mfma_scan_supported((uint32_t)dim_, metric);
     if (!direct) {
