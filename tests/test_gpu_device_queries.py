@@ -142,3 +142,8 @@ def test_device_queries_on_an_hnsw_handle_go_through_the_host(V, torch):
                                      nn.ctypes.data_as(C.POINTER(C.c_uint64)))
     assert rc == 0
     assert ids.tolist() == ref[0].tolist() and sc.tolist() == ref[1].tolist() and nn.tolist() == ref[2].tolist()
+    # a wrong query length is the reference's DimensionMismatch, reported before any query is read
+    rc = L.vl_index_search_batch_dev(h._h, C.c_void_p(dq.data_ptr()), 6, dim + 3, 10, M["euclidean"], None,
+                                     ids.ctypes.data_as(C.POINTER(C.c_uint64)), sc.ctypes.data_as(C.POINTER(C.c_double)),
+                                     nn.ctypes.data_as(C.POINTER(C.c_uint64)))
+    assert rc == 1  # VL_ERR_DIM_MISMATCH

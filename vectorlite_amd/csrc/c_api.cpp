@@ -265,14 +265,16 @@ int vl_index_search_batch_dev(const vl_index* h, const double* d_queries, uint64
                 return VL_ERR_INVALID_ARG;
             }
             std::vector<double> hq;
-            if (d_queries && nq && q_len) {
+            if (d_queries && nq && q_len && q_len == h->hnsw->dimension()) {  // (a wrong q_len is reported before any query is read)
                 hq.resize((size_t)nq * q_len);
                 if (hipMemcpy(hq.data(), d_queries, hq.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
                     vl::set_last_error("copying the device queries to the host failed");
                     return VL_ERR_DEVICE;
                 }
             }
-            return h->hnsw->search_batch(d_queries ? hq.data() : nullptr, nq, q_len, k, metric, 0, out_ids, out_scores, out_n);
+            static const double never_read = 0.0;  // nq == 0 or a wrong q_len: search_batch returns before it reads a query
+            const double* hp = !d_queries ? nullptr : (hq.empty() ? &never_read : hq.data());
+            return h->hnsw->search_batch(hp, nq, q_len, k, metric, 0, out_ids, out_scores, out_n);
         }
         return h->flat->search_batch_device(d_queries, nq, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
     });
