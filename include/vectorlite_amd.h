@@ -233,6 +233,16 @@ int vl_index_search_batch_positions(const vl_index *h, const double *queries, ui
 int vl_index_search_batch_dev(const vl_index *h, const double *d_queries, uint64_t nq, uint64_t q_len, uint64_t k,
                               int metric, uint64_t *out_pos, uint64_t *out_ids, double *out_scores, uint64_t *out_n);
 
+/* The caller's whole step (src/client.rs:393-401: embed -> index.search) for a batch: `embeddings` is [nq, dim] f32 as the
+ * model emits it (host pointer, or a device pointer on the index's GPU when embeddings_on_device != 0).  Each query is
+ * widened to f64 and, with normalize != 0, L2-normalised on the device with the arithmetic of src/embeddings.rs:169-181
+ * (bit for bit, like vl_index_add_embeddings_f32 does for rows), then searched through vl_index_search_batch_dev: with
+ * device embeddings the batch never visits the host, with host embeddings PCIe carries 4 bytes per value instead of 8.
+ * Outputs as vl_index_search_batch; row i is exactly vl_index_search of the processed query i. */
+int vl_index_search_batch_embeddings_f32(const vl_index *h, const float *embeddings, uint64_t nq, uint64_t dim,
+                                         int normalize, int embeddings_on_device, uint64_t k, int metric,
+                                         uint64_t *out_ids, double *out_scores, uint64_t *out_n);
+
 /* ---- row-sharded batched search over RCCL (north_star's config 3; no reference counterpart) ----------
  *
  * One process per GPU.  Rank r holds the contiguous row range [offset_r, offset_r + len_r) of the corpus as an

@@ -59,6 +59,7 @@ extern "C" {
     fn vl_shard_search_batch(shard: *const vl_index, comm: *mut vl_comm, queries: *const f64, nq: u64, q_len: u64, k: u64, metric: c_int, out_gpos: *mut u64, out_ids: *mut u64, out_scores: *mut f64, out_n: *mut u64) -> c_int;
     fn vl_shard_search_batch_dev(shard: *const vl_index, comm: *mut vl_comm, d_queries: *const f64, nq: u64, q_len: u64, k: u64, metric: c_int, out_gpos: *mut u64, out_ids: *mut u64, out_scores: *mut f64, out_n: *mut u64) -> c_int;
     fn vl_index_search_batch_dev(h: *const vl_index, d_queries: *const f64, nq: u64, q_len: u64, k: u64, metric: c_int, out_pos: *mut u64, out_ids: *mut u64, out_scores: *mut f64, out_n: *mut u64) -> c_int;
+    fn vl_index_search_batch_embeddings_f32(h: *const vl_index, embeddings: *const f32, nq: u64, dim: u64, normalize: c_int, embeddings_on_device: c_int, k: u64, metric: c_int, out_ids: *mut u64, out_scores: *mut f64, out_n: *mut u64) -> c_int;
 }
 
 pub const VL_COMM_ID_BYTES: usize = 128;
@@ -233,6 +234,22 @@ impl GpuFlatIndex {
             return Err(VectorLiteError::InternalError(last_error()));
         }
         Ok((0..nq).map(|q| (0..n[q] as usize).map(|i| (ids[q * k + i], scores[q * k + i])).collect()).collect())
+    }
+
+    /// The embed -> search step of `Collection::search_text` (src/client.rs:393-401) for a batch: `embeddings` is `[nq, dim]`
+    /// f32 as the model emits it; widening and L2 normalisation (src/embeddings.rs:169-181) run on the GPU, bit for bit.
+    pub fn search_batch_embeddings(&self, embeddings: &[f32], nq: usize, k: usize, metric: SimilarityMetric, normalize: bool) -> VectorLiteResult<Vec<Vec<(u64, f64)>>> {
+        let dim = self.0.dim;
+        assert_eq!(embeddings.len(), nq * dim);
+        let stride = k.min(self.len()).max(1);
+        let (mut ids, mut scores, mut n) = (vec![0u64; nq * stride], vec![0f64; nq * stride], vec![0u64; nq]);
+        let rc = unsafe {
+            vl_index_search_batch_embeddings_f32(self.0.raw, embeddings.as_ptr(), nq as u64, dim as u64, normalize as c_int, 0, k.min(stride) as u64, metric_code(metric), ids.as_mut_ptr(), scores.as_mut_ptr(), n.as_mut_ptr())
+        };
+        if rc != VL_OK {
+            return Err(VectorLiteError::InternalError(last_error()));
+        }
+        Ok((0..nq).map(|q| (0..n[q] as usize).map(|i| (ids[q * stride + i], scores[q * stride + i])).collect()).collect())
     }
 
     /// `search_batch` for queries that already sit in this GPU's memory (embeddings computed there): `d_queries` is a

@@ -147,3 +147,62 @@ def test_device_queries_on_an_hnsw_handle_go_through_the_host(V, torch):
                                      ids.ctypes.data_as(C.POINTER(C.c_uint64)), sc.ctypes.data_as(C.POINTER(C.c_double)),
                                      nn.ctypes.data_as(C.POINTER(C.c_uint64)))
     assert rc == 1  # VL_ERR_DIM_MISMATCH
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+def test_embedding_queries_equal_host_postprocessing_then_search(V, torch, normalize):
+    """vl_index_search_batch_embeddings_f32: f32 embeddings (host array or device tensor) -> widened and normalised on the
+    device with the arithmetic of src/embeddings.rs:169-181 -> searched.  Every row equals search_batch on the oracle's
+    host post-processing of the same embeddings (MFMA batch path and small-index path; HNSW: the next test)."""
+    from oracle import oracle as O
+    O.build()
+    rng = np.random.default_rng(31)
+    dim, n, nq = 384, 15000, 65
+    rows = O.embed_f32(rng.standard_normal((n, dim)).astype(np.float32), True)
+    idx = V.FlatIndex(dim)
+    idx.add_rows(np.arange(n, dtype=np.uint64), rows)
+    emb = (rng.standard_normal((nq, dim)) * 3.0).astype(np.float32)
+    emb[5] = 0.0  # a zero embedding stays zero (norm == 0: left unchanged, :176)
+    Q = O.embed_f32(emb, normalize)
+    for metric in (0, 1, 3):
+        ref = idx.search_batch(Q, 10, metric)
+        for e in (emb, torch.from_numpy(emb).to("cuda:0"), torch.from_numpy(emb)):
+            got = idx.search_batch_embeddings(e, 10, metric, normalize=normalize)
+            assert got[0].tolist() == ref[0].tolist() and got[1].tolist() == ref[1].tolist() and got[2].tolist() == ref[2].tolist()
+    small = V.FlatIndex(dim)
+    small.add_rows(np.arange(40, dtype=np.uint64), rows[:40])
+    ref = small.search_batch(Q, 10, 0)
+    got = small.search_batch_embeddings(torch.from_numpy(emb).to("cuda:0"), 10, 0, normalize=normalize)
+    assert got[0].tolist() == ref[0].tolist() and got[1].tolist() == ref[1].tolist()
+    with pytest.raises(V.DimensionMismatch):
+        idx.search_batch_embeddings(emb[:, :100], 10, 0)
+    empty = V.FlatIndex(dim)
+    assert empty.search_batch_embeddings(emb[:, :100], 10, 0)[2].tolist() == [0] * nq  # an empty flat index accepts any length
+
+
+def test_embedding_queries_on_an_hnsw_handle(V, torch):
+    import ctypes as C
+    from oracle import oracle as O
+    O.build()
+    rng = np.random.default_rng(32)
+    dim, n, nq = 64, 4000, 7
+    rows = O.embed_f32(rng.standard_normal((n, dim)).astype(np.float32), True)
+    h = V.HNSWIndex(dim, M["cosine"])
+    h.add_rows(np.arange(n, dtype=np.uint64), rows)
+    emb = rng.standard_normal((nq, dim)).astype(np.float32)
+    ref = h.search_batch(O.embed_f32(emb, True), 10, M["cosine"])
+    demb = torch.from_numpy(emb).to("cuda:0")
+    for ptr, on_dev in ((C.c_void_p(emb.ctypes.data), 0), (C.c_void_p(demb.data_ptr()), 1)):
+        ids = np.zeros((nq, 10), dtype=np.uint64)
+        sc = np.zeros((nq, 10), dtype=np.float64)
+        nn = np.zeros(nq, dtype=np.uint64)
+        rc = h._L.vl_index_search_batch_embeddings_f32(h._h, ptr, nq, dim, 1, on_dev, 10, M["cosine"],
+                                                       ids.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                       sc.ctypes.data_as(C.POINTER(C.c_double)),
+                                                       nn.ctypes.data_as(C.POINTER(C.c_uint64)))
+        assert rc == 0
+        assert ids.tolist() == ref[0].tolist() and sc.tolist() == ref[1].tolist() and nn.tolist() == ref[2].tolist()
+    rc = h._L.vl_index_search_batch_embeddings_f32(h._h, C.c_void_p(emb.ctypes.data), nq, dim - 1, 1, 0, 10, M["cosine"],
+                                                   ids.ctypes.data_as(C.POINTER(C.c_uint64)), sc.ctypes.data_as(C.POINTER(C.c_double)),
+                                                   nn.ctypes.data_as(C.POINTER(C.c_uint64)))
+    assert rc == 1  # VL_ERR_DIM_MISMATCH

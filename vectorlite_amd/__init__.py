@@ -322,6 +322,43 @@ class FlatIndex:
             return pos[:, :kc], ids[:, :kc], scores[:, :kc], n[:nq]
         return ids[:, :kc], scores[:, :kc], n[:nq]
 
+    def search_batch_embeddings(self, embeddings, k: int, metric: int = 0, normalize: bool = True):
+        """The caller's embed -> search step for a batch (src/client.rs:393-401): `embeddings` is [nq, dim] float32 as the
+        model emits it -- a numpy array, or a contiguous torch tensor on this index's GPU.  Widening to f64 and the L2
+        normalisation of src/embeddings.rs:169-181 run on the device, bit for bit, then vl_index_search_batch_dev.
+        Returns (ids, scores, n) like search_batch."""
+        on_device = False
+        try:
+            import torch
+            is_tensor = isinstance(embeddings, torch.Tensor)
+        except Exception:  # pragma: no cover
+            is_tensor = False
+        if is_tensor:
+            import torch
+            if embeddings.dtype != torch.float32 or not embeddings.is_contiguous() or embeddings.dim() != 2:
+                raise ValueError("embeddings must be a contiguous float32 [nq, dim] tensor")
+            if embeddings.is_cuda:
+                on_device = True
+                torch.cuda.current_stream(embeddings.device).synchronize()
+                ptr = C.c_void_p(embeddings.data_ptr())
+                nq, dim = embeddings.shape
+            else:
+                embeddings = embeddings.numpy()
+        if not on_device:
+            E = np.ascontiguousarray(np.asarray(embeddings, dtype=np.float32))
+            if E.ndim != 2:
+                raise ValueError("embeddings must be [nq, dim]")
+            nq, dim = E.shape
+            ptr = C.c_void_p(E.ctypes.data)
+        kk = max(min(int(k), self.len()), 1)
+        kc = min(int(k), kk)
+        ids = np.zeros((nq, kk), dtype=np.uint64)
+        scores = np.zeros((nq, kk), dtype=np.float64)
+        n = np.zeros(max(nq, 1), dtype=np.uint64)
+        _raise(self._L.vl_index_search_batch_embeddings_f32(self._h, ptr, nq, dim, 1 if normalize else 0, 1 if on_device else 0,
+                                                            kc, int(metric), _pu64(ids), _pf64(scores), _pu64(n)))
+        return ids[:, :kc], scores[:, :kc], n[:nq]
+
     def search_batch_positions(self, queries, k: int, metric: int = 0):
         """(positions, ids, scores, n), each [nq, k] ([nq] for n): the batched search_positions."""
         Q = _f64(queries)

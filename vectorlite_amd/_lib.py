@@ -18,7 +18,7 @@ SYMBOLS = [
     "vl_flat_create", "vl_flat_from_rows", "vl_hnsw_create", "vl_hnsw_create_ex", "vl_index_type", "vl_index_metric", "vl_index_search_ef", "vl_index_clone", "vl_index_destroy", "vl_index_reserve",
     "vl_index_add", "vl_index_add_bulk", "vl_index_add_embeddings_f32", "vl_index_delete", "vl_index_search", "vl_index_search_batch",
     "vl_index_len", "vl_index_is_empty", "vl_index_dimension", "vl_index_get_vector", "vl_index_max_id",
-    "vl_index_export", "vl_index_search_positions", "vl_index_search_batch_positions", "vl_index_search_batch_dev", "vl_index_hnsw_distances", "vl_hnsw_score",
+    "vl_index_export", "vl_index_search_positions", "vl_index_search_batch_positions", "vl_index_search_batch_dev", "vl_index_search_batch_embeddings_f32", "vl_index_hnsw_distances", "vl_hnsw_score",
     "vl_last_error", "vl_last_dim_mismatch", "vl_last_path", "vl_index_force_path", "vl_index_set_single_filter",
     "vl_index_set_coalescing", "vl_index_coalesce_stats", "vl_index_hnsw_walk_stats",
     "vl_vlc_open", "vl_vlc_close", "vl_vlc_name", "vl_vlc_info", "vl_vlc_side_table", "vl_vlc_read_values", "vl_vlc_build_index",
@@ -81,6 +81,7 @@ def load() -> C.CDLL:
     sig("vl_index_search_positions", i32, [vp, p_f64, u64, u64, i32, p_u64, p_u64, p_f64, p_u64])
     sig("vl_index_search_batch_positions", i32, [vp, p_f64, u64, u64, u64, i32, p_u64, p_u64, p_f64, p_u64])
     sig("vl_index_search_batch_dev", i32, [vp, vp, u64, u64, u64, i32, p_u64, p_u64, p_f64, p_u64])
+    sig("vl_index_search_batch_embeddings_f32", i32, [vp, vp, u64, u64, i32, i32, u64, i32, p_u64, p_f64, p_u64])
     sig("vl_index_hnsw_distances", i32, [vp, p_f64, u64, i32, p_u64, u64, p_u64])
     sig("vl_hnsw_score", f64, [u64, i32])
     sig("vl_last_error", C.c_char_p, [])

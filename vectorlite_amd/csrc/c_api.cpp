@@ -254,6 +254,29 @@ int vl_index_search_batch_positions(const vl_index* h, const double* queries, ui
     });
 }
 
+int vl_index_search_batch_embeddings_f32(const vl_index* h, const float* embeddings, uint64_t nq, uint64_t dim, int normalize,
+                                         int embeddings_on_device, uint64_t k, int metric, uint64_t* out_ids,
+                                         double* out_scores, uint64_t* out_n)
+{
+    return guarded([&]() -> int {
+        if (!h || (!out_n && nq)) return VL_ERR_INVALID_ARG;
+        for (uint64_t i = 0; i < nq; ++i) out_n[i] = 0;
+        const uint64_t want = h->hnsw ? h->hnsw->dimension() : h->flat->dimension();
+        const bool empty_flat = !h->hnsw && h->flat->len() == 0;  // src/index/flat.rs:99: an empty flat index accepts any length
+        if (dim != want && !empty_flat) {
+            vl::set_dim_mismatch(want, dim);
+            vl::set_last_error("Dimension mismatch: expected " + std::to_string(want) + ", got " + std::to_string(dim));
+            return VL_ERR_DIM_MISMATCH;
+        }
+        if (nq == 0 || empty_flat) return VL_OK;
+        const int device = h->hnsw ? h->hnsw->device() : h->flat->device();
+        return vl::search_embeddings_f32(device, dim, embeddings, nq, normalize != 0, embeddings_on_device != 0,
+                                         [&](const double* d_q, uint64_t n) -> int {
+                                             return vl_index_search_batch_dev(h, d_q, n, dim, k, metric, nullptr, out_ids, out_scores, out_n);
+                                         });
+    });
+}
+
 int vl_index_search_batch_dev(const vl_index* h, const double* d_queries, uint64_t nq, uint64_t q_len, uint64_t k,
                               int metric, uint64_t* out_pos, uint64_t* out_ids, double* out_scores, uint64_t* out_n)
 {

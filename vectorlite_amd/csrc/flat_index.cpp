@@ -1422,4 +1422,38 @@ int add_embeddings_f32(int device, uint64_t dim, const uint64_t* ids, const floa
     return OK;
 }
 
+int search_embeddings_f32(int device, uint64_t dim, const float* emb, uint64_t nq, bool normalize, bool emb_on_device,
+                          const std::function<int(const double*, uint64_t)>& search)
+{
+    if (nq == 0) return OK;
+    if (!emb && dim) return ERR_INVALID_ARG;
+    if (dim == 0 || nq > (1ull << 31) / std::max<uint64_t>(dim, 1) * 64) {  // 16 GiB of f64 queries: not a batch
+        set_last_error("query batch too large (or dimension 0)");
+        return ERR_INVALID_ARG;
+    }
+    VL_HIP(hipSetDevice(device));
+    struct Scratch {
+        hipStream_t st = nullptr;
+        double* rows = nullptr;
+        float* staged = nullptr;
+        ~Scratch()
+        {
+            if (rows) (void)hipFree(rows);
+            if (staged) (void)hipFree(staged);
+            if (st) (void)hipStreamDestroy(st);
+        }
+    } sc;
+    VL_HIP(hipStreamCreateWithFlags(&sc.st, hipStreamNonBlocking));
+    VL_HIP(hipMalloc(&sc.rows, nq * dim * sizeof(double)));
+    const float* src = emb;
+    if (!emb_on_device) {
+        VL_HIP(hipMalloc(&sc.staged, nq * dim * sizeof(float)));
+        VL_HIP(hipMemcpyAsync(sc.staged, emb, nq * dim * sizeof(float), hipMemcpyHostToDevice, sc.st));
+        src = sc.staged;
+    }
+    VL_HIP(launch_embed_f32(sc.st, src, nq, (uint32_t)dim, normalize, sc.rows));
+    VL_HIP(hipStreamSynchronize(sc.st));
+    return search(sc.rows, nq);
+}
+
 }  // namespace vl

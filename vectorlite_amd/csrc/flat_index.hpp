@@ -235,4 +235,10 @@ private:
 int add_embeddings_f32(int device, uint64_t dim, const uint64_t* ids, const float* emb, uint64_t n, bool normalize,
                        bool emb_on_device, const std::function<int(const uint64_t*, const double*, uint64_t)>& append);
 
+// NEW: the query side of the same step (src/client.rs:393-401: embed -> index.search): nq f32 embeddings [nq, dim] (host or
+// device) are widened and optionally L2-normalised on the device exactly like add_embeddings_f32 does for rows, then handed
+// to `search(device f64 queries, count)` -- for the flat index that is search_batch_device: the batch never visits the host.
+int search_embeddings_f32(int device, uint64_t dim, const float* emb, uint64_t nq, bool normalize, bool emb_on_device,
+                          const std::function<int(const double*, uint64_t)>& search);
+
 }  // namespace vl
