@@ -925,7 +925,9 @@ def test_concurrent_writers_and_coalesced_readers_do_not_deadlock_or_corrupt(V, 
 
 
 def _embedding_cases(rng):
-    for n, dim in [(1, 1), (5, 3), (63, 100), (64, 64), (65, 65), (257, 384), (130, 1000)]:
+    # up to 16384 rows take the wave-per-row kernel (k_embed_f32_rows: a batch of queries, a small add), more the
+    # lane-per-row one (k_embed_f32: bulk ingest); rows longer than 2048 values always the latter
+    for n, dim in [(1, 1), (5, 3), (63, 100), (64, 64), (65, 65), (257, 384), (130, 1000), (17000, 48), (9, 2500)]:
         e = rng.standard_normal((n, dim)).astype(np.float32)
         if n > 4:
             e[2] = 0.0                       # norm == 0: left as it is (src/embeddings.rs:176-180)

@@ -1432,23 +1432,67 @@ int search_embeddings_f32(int device, uint64_t dim, const float* emb, uint64_t n
         return ERR_INVALID_ARG;
     }
     VL_HIP(hipSetDevice(device));
+    // conversion scratch (a stream, the f64 queries, the staged f32 embeddings) comes from a small process-wide pool: a
+    // hipMalloc / hipFree pair per call would cost more than the conversion kernel and synchronise the device
     struct Scratch {
+        int device = 0;
         hipStream_t st = nullptr;
         double* rows = nullptr;
+        size_t rows_cap = 0;
         float* staged = nullptr;
+        size_t staged_cap = 0;
         ~Scratch()
         {
+            (void)hipSetDevice(device);
             if (rows) (void)hipFree(rows);
             if (staged) (void)hipFree(staged);
             if (st) (void)hipStreamDestroy(st);
         }
-    } sc;
-    VL_HIP(hipStreamCreateWithFlags(&sc.st, hipStreamNonBlocking));
-    VL_HIP(hipMalloc(&sc.rows, nq * dim * sizeof(double)));
+    };
+    static std::mutex pool_mu;
+    static std::vector<std::unique_ptr<Scratch>> pool;  // idle scratches (at most 8 are kept)
+    std::unique_ptr<Scratch> scp;
+    {
+        std::lock_guard<std::mutex> g(pool_mu);
+        for (size_t i = 0; i < pool.size(); ++i)
+            if (pool[i]->device == device) {
+                scp = std::move(pool[i]);
+                pool.erase(pool.begin() + (long)i);
+                break;
+            }
+    }
+    if (!scp) {
+        scp.reset(new Scratch());
+        scp->device = device;
+        VL_HIP(hipStreamCreateWithFlags(&scp->st, hipStreamNonBlocking));
+    }
+    struct Return {
+        std::unique_ptr<Scratch>& p;
+        ~Return()
+        {
+            std::lock_guard<std::mutex> g(pool_mu);
+            if (p && pool.size() < 8) pool.push_back(std::move(p));
+        }
+    } ret{scp};
+    Scratch& sc = *scp;
+    const size_t need = (size_t)nq * dim;
+    if (sc.rows_cap < need) {
+        if (sc.rows) (void)hipFree(sc.rows);
+        sc.rows = nullptr;
+        sc.rows_cap = 0;
+        VL_HIP(hipMalloc(&sc.rows, need * sizeof(double)));
+        sc.rows_cap = need;
+    }
     const float* src = emb;
     if (!emb_on_device) {
-        VL_HIP(hipMalloc(&sc.staged, nq * dim * sizeof(float)));
-        VL_HIP(hipMemcpyAsync(sc.staged, emb, nq * dim * sizeof(float), hipMemcpyHostToDevice, sc.st));
+        if (sc.staged_cap < need) {
+            if (sc.staged) (void)hipFree(sc.staged);
+            sc.staged = nullptr;
+            sc.staged_cap = 0;
+            VL_HIP(hipMalloc(&sc.staged, need * sizeof(float)));
+            sc.staged_cap = need;
+        }
+        VL_HIP(hipMemcpyAsync(sc.staged, emb, need * sizeof(float), hipMemcpyHostToDevice, sc.st));
         src = sc.staged;
     }
     VL_HIP(launch_embed_f32(sc.st, src, nq, (uint32_t)dim, normalize, sc.rows));
