@@ -31,6 +31,8 @@ while time.time() < t_end:
     bd = idx.search_batch_device(dq, 10, 0); searches += 40
     assert bd[0].tolist() == b[0].tolist() and bd[1].tolist() == b[1].tolist()
     del dq
+    eb = idx.search_batch_embeddings(Q.astype(np.float32), 10, 0); searches += 40  # f32 embeddings: device-side post-processing, pooled scratch
+    assert eb[2].tolist() == [10] * 40
     idx.set_single_filter("bf16"); idx.search_arrays(Q[1], 10, 0); idx.set_single_filter("f32")
     idx.search_arrays(Q[2], 100, 1); idx.search_arrays(Q[2], 700, 1)
     idx.set_coalescing(32, 100)
