@@ -135,11 +135,24 @@ int vl_index_delete(vl_index *h, uint64_t id);
 int vl_index_search(const vl_index *h, const double *query, uint64_t q_len, uint64_t k, int metric,
                     uint64_t *out_ids, double *out_scores, uint64_t *out_n);
 
+/* vl_index_search with an explicit output capacity: writes min(k, len, out_capacity) results -- the first
+ * out_capacity entries of what vl_index_search would write (`truncate(k)`, src/index/flat.rs:117, applied once
+ * more).  A caller that sized its buffers from an earlier vl_index_len() cannot be overrun by a concurrent add():
+ * the bound is the caller's own number, not the index's length at search time.  The Rust / Python / C bindings of
+ * this repository all call this form. */
+int vl_index_search_cap(const vl_index *h, const double *query, uint64_t q_len, uint64_t k, int metric,
+                        uint64_t out_capacity, uint64_t *out_ids, double *out_scores, uint64_t *out_n);
+
 /* NEW capability (the reference has no batch entry, src/lib.rs:224-245): nq independent
  * searches, each with exactly vl_index_search's result.  queries is [nq, q_len];
  * out_ids/out_scores are [nq, k] (row stride k), out_n is [nq]. */
 int vl_index_search_batch(const vl_index *h, const double *queries, uint64_t nq, uint64_t q_len, uint64_t k,
                           int metric, uint64_t *out_ids, double *out_scores, uint64_t *out_n);
+
+/* The batch form with an explicit row capacity: out_ids / out_scores are [nq, out_stride]; row i receives
+ * min(k, len, out_stride) entries, out_n[i] says how many. */
+int vl_index_search_batch_cap(const vl_index *h, const double *queries, uint64_t nq, uint64_t q_len, uint64_t k,
+                              int metric, uint64_t out_stride, uint64_t *out_ids, double *out_scores, uint64_t *out_n);
 
 uint64_t vl_index_len(const vl_index *h);      /* len()       src/index/flat.rs:121-123 */
 int vl_index_is_empty(const vl_index *h);      /* is_empty()  src/index/flat.rs:125-127 */

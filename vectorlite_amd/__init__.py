@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import enum
+import threading
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
@@ -184,6 +185,7 @@ class FlatIndex:
         self._L = _lib.load()
         self._meta: Dict[int, Tuple[str, Any]] = {}
         self._h = C.c_void_p()
+        self._tls = threading.local()
         self.device = device
         if _handle is not None:
             self._h = _handle
@@ -259,18 +261,32 @@ class FlatIndex:
         return out.value
 
     # ---- array-level entry points -----------------------------------------------------------
+    def _out_buffers(self, k: int):
+        """Per-thread output buffers of the single-query call (ids, scores, count) with their raw addresses:
+        made once per thread, regrown only for a larger k.  vl_index_search_cap bounds what the library writes by
+        the buffers' own capacity, whatever the index length is by the time the search runs."""
+        tl = self._tls
+        buf = getattr(tl, "buf", None)
+        if buf is None or buf[0] < k:
+            cap = max(64, min(int(k), max(self.len(), 1)))
+            ids = np.empty(cap, dtype=np.uint64)
+            scores = np.empty(cap, dtype=np.float64)
+            n = C.c_uint64(0)
+            buf = (cap, ids, scores, n, ids.ctypes.data, scores.ctypes.data, C.addressof(n))
+            tl.buf = buf
+        return buf
+
     def search_arrays(self, query, k: int, metric: int = 0) -> Tuple[np.ndarray, np.ndarray]:
-        q = _f64(query).ravel()
-        # The ABI writes min(k, len at search time) entries and has no capacity argument: k is clamped to the
-        # buffer, so a concurrent add() from another thread (ctypes drops the GIL) between len() and the search
-        # cannot make the library write past it -- results for a smaller k are a prefix of those for a larger k.
-        m = max(min(int(k), self.len()), 1)
-        ids = np.empty(m, dtype=np.uint64)
-        scores = np.empty(m, dtype=np.float64)
-        n = C.c_uint64(0)
-        _raise(self._L.vl_index_search(self._h, _pf64(q), q.size, min(int(k), m), int(metric), _pu64(ids), _pf64(scores),
-                                       C.byref(n)))
-        return ids[: n.value].copy(), scores[: n.value].copy()
+        q = query
+        if not (type(q) is np.ndarray and q.dtype == np.float64 and q.ndim == 1 and q.flags.c_contiguous):
+            q = _f64(query).ravel()
+        k = min(max(int(k), 0), 1 << 62)
+        cap, ids, scores, n, p_ids, p_scores, p_n = self._out_buffers(k)
+        rc = self._L.vl_index_search_cap(self._h, q.ctypes.data, q.size, k, metric, cap, p_ids, p_scores, p_n)
+        if rc:
+            _raise(rc)
+        m = n.value
+        return ids[:m].copy(), scores[:m].copy()
 
     def search_positions(self, query, k: int, metric: int = 0):
         """(positions, ids, scores): positions are storage positions, for row-shard merging."""

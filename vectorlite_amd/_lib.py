@@ -16,7 +16,7 @@ SO_PATH = os.environ.get("VL_LIB_PATH") or os.path.join(_HERE, "libvectorlite_am
 # every symbol include/vectorlite_amd.h declares
 SYMBOLS = [
     "vl_flat_create", "vl_flat_from_rows", "vl_hnsw_create", "vl_hnsw_create_ex", "vl_index_type", "vl_index_metric", "vl_index_search_ef", "vl_index_clone", "vl_index_destroy", "vl_index_reserve",
-    "vl_index_add", "vl_index_add_bulk", "vl_index_add_embeddings_f32", "vl_index_delete", "vl_index_search", "vl_index_search_batch",
+    "vl_index_add", "vl_index_add_bulk", "vl_index_add_embeddings_f32", "vl_index_delete", "vl_index_search", "vl_index_search_batch", "vl_index_search_cap", "vl_index_search_batch_cap",
     "vl_index_len", "vl_index_is_empty", "vl_index_dimension", "vl_index_get_vector", "vl_index_max_id",
     "vl_index_export", "vl_index_search_positions", "vl_index_search_batch_positions", "vl_index_search_batch_dev", "vl_index_search_batch_embeddings_f32", "vl_index_hnsw_distances", "vl_hnsw_score",
     "vl_last_error", "vl_last_dim_mismatch", "vl_last_path", "vl_index_force_path", "vl_index_set_single_filter",
@@ -72,6 +72,9 @@ def load() -> C.CDLL:
     sig("vl_index_delete", i32, [vp, u64])
     sig("vl_index_search", i32, [vp, p_f64, u64, u64, i32, p_u64, p_f64, p_u64])
     sig("vl_index_search_batch", i32, [vp, p_f64, u64, u64, u64, i32, p_u64, p_f64, p_u64])
+    # the hot single-query entry takes raw addresses (no ctypes pointer objects made per call)
+    sig("vl_index_search_cap", i32, [vp, vp, u64, u64, i32, u64, vp, vp, vp])
+    sig("vl_index_search_batch_cap", i32, [vp, p_f64, u64, u64, u64, i32, u64, p_u64, p_f64, p_u64])
     sig("vl_index_len", u64, [vp])
     sig("vl_index_is_empty", i32, [vp])
     sig("vl_index_dimension", u64, [vp])

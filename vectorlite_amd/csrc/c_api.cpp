@@ -223,6 +223,41 @@ int vl_index_search(const vl_index* h, const double* query, uint64_t q_len, uint
     });
 }
 
+int vl_index_search_cap(const vl_index* h, const double* query, uint64_t q_len, uint64_t k, int metric,
+                        uint64_t out_capacity, uint64_t* out_ids, double* out_scores, uint64_t* out_n)
+{
+    // results for a smaller k are a prefix of those for a larger k (one total order: score desc, insertion order):
+    // truncating k to the capacity IS writing the first `out_capacity` entries of the k results
+    return vl_index_search(h, query, q_len, k < out_capacity ? k : out_capacity, metric, out_ids, out_scores, out_n);
+}
+
+int vl_index_search_batch_cap(const vl_index* h, const double* queries, uint64_t nq, uint64_t q_len, uint64_t k,
+                              int metric, uint64_t out_stride, uint64_t* out_ids, double* out_scores, uint64_t* out_n)
+{
+    if (k >= out_stride)  // rows are then exactly out_stride apart, which is the plain call's layout for k = out_stride
+        return vl_index_search_batch(h, queries, nq, q_len, out_stride, metric, out_ids, out_scores, out_n);
+    return guarded([&]() -> int {
+        if (!h || (!out_n && nq)) return VL_ERR_INVALID_ARG;
+        if (nq == 0) return VL_OK;
+        // k < out_stride: answer into [nq, kk] scratch (kk = min(k, len): nothing larger is ever written) and spread the rows
+        const uint64_t len = h->hnsw ? h->hnsw->len() : h->flat->len();
+        const uint64_t kk = k < len ? k : len;
+        std::vector<uint64_t> ids(nq * kk);
+        std::vector<double> scores(nq * kk);
+        const int rc = h->hnsw ? h->hnsw->search_batch(queries, nq, q_len, kk, metric, 0, ids.data(), scores.data(), out_n)
+                               : h->flat->search_batch(queries, nq, q_len, kk, metric, nullptr, ids.data(), scores.data(), out_n);
+        if (rc != VL_OK) return rc;
+        for (uint64_t q = 0; q < nq; ++q) {
+            const uint64_t m = out_n[q] < kk ? out_n[q] : kk;
+            for (uint64_t j = 0; j < m; ++j) {
+                if (out_ids) out_ids[q * out_stride + j] = ids[q * kk + j];
+                if (out_scores) out_scores[q * out_stride + j] = scores[q * kk + j];
+            }
+        }
+        return VL_OK;
+    });
+}
+
 int vl_index_search_positions(const vl_index* h, const double* query, uint64_t q_len, uint64_t k, int metric,
                               uint64_t* out_pos, uint64_t* out_ids, double* out_scores, uint64_t* out_n)
 {

@@ -600,7 +600,9 @@ int GpuFlatIndex::search_direct(const double* query, uint64_t q_len, uint64_t k,
     VL_HIP(hipSetDevice(device_));
     Workspace* ws = acquire_ws();
     if (!ws) return ERR_DEVICE;
+    active_searches_.fetch_add(1, std::memory_order_relaxed);
     const int rc = search_locked(ws, query, k_eff, metric, out_pos, out_ids, out_scores, out_n, false);
+    active_searches_.fetch_sub(1, std::memory_order_relaxed);
     if (rc != OK) (void)hipStreamSynchronize(ws->stream);
     release_ws(ws);
     return rc;
@@ -756,7 +758,7 @@ int GpuFlatIndex::search_locked(Workspace* ws, const double* query, uint64_t k_e
     const uint64_t n = ids_.size();
     hipStream_t st = ws->stream;
 
-    // stage the query: f64 (exact kernels) and f32 zero-padded to ld (scan)
+    // stage the query in the pinned block: the f64 values, then the norm
     double qq = 0.0, qmax = 0.0;
     bool q_finite = true;
     for (uint64_t i = 0; i < dim_; ++i) {
@@ -769,10 +771,18 @@ int GpuFlatIndex::search_locked(Workspace* ws, const double* query, uint64_t k_e
     }
     const double q_norm = std::sqrt(qq);
     const bool q_in_domain = q_finite && qmax <= DOMAIN_MAX_ABS && (q_norm == 0.0 || q_norm >= DOMAIN_MIN_NORM);
-    // one small H2D copy per query (the query and, behind it, its norm); the scan kernel rounds its
-    // f32 copy of the query itself
     ws->h_q64[dim_] = q_norm;
-    VL_HIP(hipMemcpyAsync(ws->d_q64, ws->h_q64, (dim_ + 1) * sizeof(double), hipMemcpyHostToDevice, st));
+    // The f32 scan takes its query in the kernel arguments and the finalize kernel reads the pinned block itself,
+    // so the common case needs NO copy in front of the kernels.  Every other kernel (bf16 filter, the k > 60 lists,
+    // the exact scan: all workgroups read the query) wants it in device memory: copied on first use.
+    bool q_on_device = false;
+    auto q_to_device = [&]() -> int {
+        if (!q_on_device) {
+            VL_HIP(hipMemcpyAsync(ws->d_q64, ws->h_q64, (dim_ + 1) * sizeof(double), hipMemcpyHostToDevice, st));
+            q_on_device = true;
+        }
+        return OK;
+    };
 
     const int forced = force_path_.load();
     const bool fast_ok = !skip_fast && forced == 0 && k_eff <= (uint64_t)KFAST_MAX && n_out_of_domain_ == 0 &&
@@ -785,6 +795,7 @@ int GpuFlatIndex::search_locked(Workspace* ws, const double* query, uint64_t k_e
     if (fast_ok && single_filter_.load() == 1 && scan_bf16_supported((uint32_t)dim_, metric) &&
         !(bf16_tries_.load() >= 64 && bf16_fails_.load() * 3 > bf16_tries_.load())) {
         VL_TRY(ensure_bf16_slab(false));
+        VL_TRY(q_to_device());
         const bool prof = profile_.load();
         int grid = 0;
         if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
@@ -825,17 +836,36 @@ int GpuFlatIndex::search_locked(Workspace* ws, const double* query, uint64_t k_e
     if (fast_ok) {
         const bool prof = profile_.load();
         ScanPlan plan;
+        // one search = two launches: the scan (query in its kernel arguments) and the finalize kernel, which reads
+        // the f64 query from the pinned block, writes the result block into pinned memory and stamps it; the host
+        // waits for the stamp, not for the stream
+        const bool qarg = scan_takes_qarg(ld_);
+        const float* q32 = nullptr;
+        if (qarg) {
+            if (ws->q32.size() < ld_) ws->q32.assign(ld_, 0.0f);
+            for (uint64_t i = 0; i < dim_; ++i) ws->q32[i] = (float)query[i];  // nearest even, like load_q4 on the device
+            q32 = ws->q32.data();
+        } else {
+            VL_TRY(q_to_device());
+        }
+        const double* fq = q_on_device ? ws->d_q64 : ws->h_q64;
+        uint32_t seq = ++ws->seq;
+        if (seq == 0) seq = ++ws->seq;
+        ws->h_result->seq = 0;
         if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
-        VL_HIP(launch_scan(st, metric, d_slab_, d_inv_norm_, ws->d_q64, n, (uint32_t)dim_, ld_, ws->d_partials, &plan));
+        VL_HIP(launch_scan(st, metric, d_slab_, d_inv_norm_, ws->d_q64, n, (uint32_t)dim_, ld_, ws->d_partials, &plan, q32));
         if (prof) VL_HIP(hipEventRecord(ws->ev1, st));
-        // the finalize kernel stores the 1 KB result block straight into pinned host memory
-        VL_HIP(launch_merge_finalize(st, metric, ws->d_partials, plan.grid, 1, d_master_, ws->d_q64,
-                                     ws->d_q64 + dim_, (uint32_t)dim_, n, (uint32_t)k_eff, max_row_norm_,
-                                     ws->h_result));
-        VL_HIP(hipStreamSynchronize(st));
+        VL_HIP(launch_merge_finalize(st, metric, ws->d_partials, plan.grid, 1, d_master_, fq, fq + dim_, (uint32_t)dim_, n,
+                                     (uint32_t)k_eff, max_row_norm_, ws->h_result, 0.0, seq));
+        VL_TRY(wait_result(ws, seq));
         if (prof) {
             float ms = 0.f;
-            VL_HIP(hipEventElapsedTime(&ms, ws->ev0, ws->ev1));
+            hipError_t pe = hipEventElapsedTime(&ms, ws->ev0, ws->ev1);
+            if (pe == hipErrorNotReady) {
+                VL_HIP(hipEventSynchronize(ws->ev1));
+                pe = hipEventElapsedTime(&ms, ws->ev0, ws->ev1);
+            }
+            VL_HIP(pe);
             std::lock_guard<std::mutex> g(prof_mu_);
             prof_n_ += 1;
             prof_ms_ += ms;
@@ -866,6 +896,7 @@ int GpuFlatIndex::search_locked(Workspace* ws, const double* query, uint64_t k_e
         q_in_domain && n > 4 * (uint64_t)KP) {
         int parts = (int)std::min<uint64_t>(4, (k_eff + 36 + KP - 1) / KP);
         ScanPlan plan;
+        VL_TRY(q_to_device());
         VL_HIP(launch_scan(st, metric, d_slab_, d_inv_norm_, ws->d_q64, n, (uint32_t)dim_, ld_, ws->d_partials, &plan));
         while (parts < 4 && plan.grid % parts != 0) ++parts;  // partitions are equal runs of workgroup lists
         if (plan.grid % parts == 0 && plan.grid >= parts) {
@@ -896,6 +927,7 @@ int GpuFlatIndex::search_locked(Workspace* ws, const double* query, uint64_t k_e
 
     std::vector<uint32_t> pos;
     std::vector<double> scores;
+    VL_TRY(q_to_device());
     VL_TRY(run_exact(ws, metric, n, k_eff, &pos, &scores));
     for (uint64_t i = 0; i < k_eff; ++i) {
         if (pos[i] >= n) {
@@ -907,6 +939,39 @@ int GpuFlatIndex::search_locked(Workspace* ws, const double* query, uint64_t k_e
         out_scores[i] = scores[i];
     }
     *out_n = k_eff;
+    return OK;
+}
+
+// Completion of a single search.  The finalize kernel stores the result block in pinned host memory and then the
+// stamp (system-scope release); a lone caller polls the stamp -- the block is readable a PCIe write after the kernel's
+// last store, where hipStreamSynchronize adds the runtime's own completion path (signal, interrupt or its polling
+// interval) on top.  The poll is bounded: the stream is queried now and then so that a failed launch surfaces as an
+// error instead of a hang, and when several searches are in flight the threads sleep in hipStreamSynchronize instead
+// of each burning a core.
+int GpuFlatIndex::wait_result(Workspace* ws, uint32_t seq) const
+{
+    const uint32_t* stamp = &ws->h_result->seq;
+    auto stamped = [&]() { return __atomic_load_n(stamp, __ATOMIC_ACQUIRE) == seq; };
+    if (active_searches_.load(std::memory_order_relaxed) <= SPIN_MAX_SEARCHERS) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t it = 1;; ++it) {
+            if (stamped()) return OK;
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#endif
+            if ((it & 0x3FFF) == 0) {  // every ~16 k polls (some hundred microseconds)
+                const hipError_t q = hipStreamQuery(ws->stream);
+                if (q == hipSuccess) break;            // stream drained: the stamp is there, or the launch was lost
+                if (q != hipErrorNotReady) VL_HIP(q);
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(SPIN_MAX_MS)) break;
+            }
+        }
+    }
+    VL_HIP(hipStreamSynchronize(ws->stream));
+    if (!stamped()) {
+        set_last_error("the finalize kernel completed without stamping its result block");
+        return ERR_DEVICE;
+    }
     return OK;
 }
 

@@ -75,6 +75,8 @@ struct Workspace {
     uint64_t* d_dists = nullptr;
     size_t hn_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<float> q32;   // the f32 query handed to k_scan in its kernel arguments
+    uint32_t seq = 0;         // stamp of the last single search issued from this workspace (h_result->seq)
     // large-batch MFMA path (lazy)
     MfmaScratch mf;
     double* mf_d_q64 = nullptr;             // [MFMA_MAX_BATCH, dim] queries, then their norms
@@ -174,6 +176,7 @@ private:
                       uint64_t* out_ids, double* out_scores, uint64_t* out_n, bool skip_fast) const;
     int run_exact(Workspace* ws, int metric, uint64_t n, uint64_t k_eff, std::vector<uint32_t>* pos,
                   std::vector<double>* scores) const;
+    int wait_result(Workspace* ws, uint32_t seq) const;
     int ensure_bf16_slab(bool frag_major) const;  // lazily builds the bf16 slab (row-major, or MFMA fragment order) a filter streams
     int ensure_mfma_scratch(Workspace* ws) const;
     int search_batch_locked(const double* queries, uint64_t nq, uint64_t q_len, uint64_t k, int metric, uint64_t* out_pos,
@@ -224,6 +227,11 @@ private:
     std::atomic<int> single_filter_{0};
     mutable std::atomic<uint64_t> bf16_tries_{0}, bf16_fails_{0};
     std::atomic<bool> profile_{false};
+    // single searches in flight on this handle: up to SPIN_MAX_SEARCHERS of them poll their result stamp,
+    // more than that sleep in hipStreamSynchronize (wait_result)
+    static constexpr int SPIN_MAX_SEARCHERS = 2;
+    static constexpr int SPIN_MAX_MS = 200;
+    mutable std::atomic<int> active_searches_{0};
     mutable std::mutex prof_mu_;
     mutable uint64_t prof_n_ = 0;
     mutable double prof_ms_ = 0.0;

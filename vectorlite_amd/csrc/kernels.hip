@@ -25,6 +25,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <mutex>
 #include <type_traits>
@@ -124,11 +125,11 @@ __device__ __forceinline__ float group_reduce(float a)
     return a;
 }
 
-// Specialised: ld4 == G * VPL float4 per row, U row groups in flight per wave.
+// Specialised: ld4 == G * VPL float4 per row, U row groups in flight per wave.  `qv` is the lane's slice of the
+// f32 query (columns c + G j), loaded by the kernel entry that wraps this body.
 template <int METRIC, int G, int VPL, int U>
-__global__ __launch_bounds__(256) void k_scan(const f32x4* __restrict__ slab, const float* __restrict__ inv_norm,
-                                              const double* __restrict__ q64, uint32_t dim, uint32_t n,
-                                              Cand32* __restrict__ out)
+__device__ __forceinline__ void scan_body(const f32x4* __restrict__ slab, const float* __restrict__ inv_norm,
+                                          const f32x4 (&qv)[VPL], uint32_t n, Cand32* __restrict__ out)
 {
     constexpr int RPS = WAVE / G;  // rows per step of one wave
     constexpr uint32_t LD4 = G * VPL;
@@ -137,10 +138,6 @@ __global__ __launch_bounds__(256) void k_scan(const f32x4* __restrict__ slab, co
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const int g = lane / G, c = lane % G;
-
-    f32x4 qv[VPL];
-#pragma unroll
-    for (int j = 0; j < VPL; ++j) qv[j] = load_q4(q64, c + G * j, dim);
 
     const uint32_t n_steps = (n + RPS - 1) / RPS;
     const uint32_t n_waves = gridDim.x * 4;
@@ -185,6 +182,39 @@ __global__ __launch_bounds__(256) void k_scan(const f32x4* __restrict__ slab, co
         e.pos = L.pos;
         out[(size_t)blockIdx.x * KP + lane] = e;
     }
+}
+
+// K1, the single-query form: the f32 query travels IN THE KERNEL ARGUMENTS (rows of up to SCAN_QARG_FLOATS padded
+// columns = 3 KB of the 4 KB kernarg segment), rounded on the host exactly as load_q4 rounds it here (f64 -> f32,
+// nearest even).  No H2D copy precedes the scan: a search is this launch + the finalize kernel.
+struct alignas(16) ScanQArg {
+    float v[SCAN_QARG_FLOATS];
+};
+
+template <int METRIC, int G, int VPL, int U>
+__global__ __launch_bounds__(256) void k_scan(const f32x4* __restrict__ slab, const float* __restrict__ inv_norm,
+                                              uint32_t n, Cand32* __restrict__ out, const ScanQArg qa)
+{
+    static_assert(G * VPL * 4 <= SCAN_QARG_FLOATS, "row too long for the kernarg query");
+    const int c = lane_id() % G;
+    f32x4 qv[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) qv[j] = *reinterpret_cast<const f32x4*>(&qa.v[4 * (c + G * j)]);
+    scan_body<METRIC, G, VPL, U>(slab, inv_norm, qv, n, out);
+}
+
+// The same scan with the f64 query in device memory (rows longer than the kernarg form holds; the multi-list
+// k > 60 path, which stages the query on the device anyway).
+template <int METRIC, int G, int VPL, int U>
+__global__ __launch_bounds__(256) void k_scan_q64(const f32x4* __restrict__ slab, const float* __restrict__ inv_norm,
+                                                  const double* __restrict__ q64, uint32_t dim, uint32_t n,
+                                                  Cand32* __restrict__ out)
+{
+    const int c = lane_id() % G;
+    f32x4 qv[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) qv[j] = load_q4(q64, c + G * j, dim);
+    scan_body<METRIC, G, VPL, U>(slab, inv_norm, qv, n, out);
 }
 
 // Generic: any ld4 (float4 per row), G = lanes per row (power of two <= 64).
@@ -372,6 +402,125 @@ __device__ __forceinline__ void rescore_rows(const double* __restrict__ master, 
     }
 }
 
+// The finalize kernels' rescoring (1024 threads): the same reference arithmetic with the serial part cut down to
+// what the reference makes serial.  `a += x * y` under -ffp-contract=off is t = fl(x * y); a = fl(a + t): the
+// products do not depend on the running sum, so ALL threads compute them while they move the rows through LDS
+// (64 rows x 48 columns per tile), and one lane per row then only ADDS them in index order.  Cosine's three sums
+// (x.y, x.x, y.y) are walked by three different waves at the same time.  Per row that leaves `dim` dependent f64
+// adds (~2 us at dim 384) where rescore_rows walks dim x (2 LDS reads + 6 dependent f64 operations).
+constexpr int RP_CH = 48;               // columns per LDS tile (row stride 49 doubles: conflict-free ds_read_b64)
+constexpr int RP_NCH = 8;               // tiles per block of columns fetched from HBM together
+constexpr int RP_BW = RP_CH * RP_NCH;   // 384 columns: one memory round trip for a dim-384 row
+constexpr int RP_PER = KP * RP_CH / 1024;
+static_assert(KP * RP_CH % 1024 == 0, "tile elements divide evenly over the workgroup");
+
+template <int METRIC>
+struct RescoreLds {
+    double tA[KP][RP_CH + 1];                                 // the summands of `a`
+    double tB[METRIC == COSINE ? KP : 1][RP_CH + 1];          // cosine: x * x
+    double qblk[RP_BW];                                       // the query's columns of the current block
+    double qq[METRIC == COSINE ? RP_BW : 1];                  // cosine: y * y
+    double b[KP];
+    double c;
+};
+
+template <int METRIC>
+__device__ __forceinline__ void rescore_rows_par(const double* __restrict__ master, const double* __restrict__ q64,
+                                                 uint32_t dim, const uint32_t* sh_pos, int n_rows,
+                                                 RescoreLds<METRIC>& S, Acc64<METRIC>& A)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1), wave = tid >> 6;
+    A.init();
+    if (n_rows <= 0) return;  // workgroup-uniform (an all-sentinel candidate list)
+    // what this thread accumulates: wave 0 the rows' `a`, wave 1 their `b`, wave 2 the query's `c` (cosine)
+    double acc = (METRIC == COSINE) ? 0.0 : -0.0;
+    for (uint32_t g0 = 0; g0 < dim; g0 += RP_BW) {
+        double pre[RP_NCH][RP_PER];
+#pragma unroll
+        for (int p = 0; p < RP_NCH; ++p) {
+            const uint32_t c0 = g0 + p * RP_CH;
+#pragma unroll
+            for (int i = 0; i < RP_PER; ++i) {
+                // clamped, never predicated (a load under a condition is waited for before the next one issues):
+                // rows >= n_rows are not walked and columns >= dim not summed, so the duplicates are unused
+                const int idx = tid + i * 1024;
+                int r = idx / RP_CH;
+                r = r < n_rows ? r : n_rows - 1;
+                uint32_t col = c0 + (uint32_t)(idx % RP_CH);
+                col = col < dim ? col : dim - 1;
+                pre[p][i] = master[(size_t)sh_pos[r] * dim + col];
+            }
+        }
+        double qv = 0.0;
+        if (tid < RP_BW) {
+            const uint32_t col = g0 + (uint32_t)tid;
+            qv = q64[col < dim ? col : dim - 1];
+        }
+        __syncthreads();  // the previous block's qblk / tiles are consumed
+        if (tid < RP_BW) {
+            S.qblk[tid] = qv;
+            if (METRIC == COSINE) S.qq[tid] = qv * qv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < RP_NCH; ++p) {
+            const uint32_t c0 = g0 + p * RP_CH;
+            if (c0 >= dim) break;  // workgroup-uniform
+            const uint32_t cw = (dim - c0) < (uint32_t)RP_CH ? (dim - c0) : (uint32_t)RP_CH;
+            if (p) __syncthreads();  // the previous tile is consumed
+#pragma unroll
+            for (int i = 0; i < RP_PER; ++i) {
+                const int idx = tid + i * 1024;
+                const int r = idx / RP_CH, cc = idx % RP_CH;
+                const double x = pre[p][i], y = S.qblk[p * RP_CH + cc];
+                if (METRIC == COSINE) {
+                    S.tA[r][cc] = x * y;
+                    S.tB[r][cc] = x * x;
+                } else if (METRIC == EUCLIDEAN) {
+                    const double d = x - y;
+                    S.tA[r][cc] = d * d;
+                } else if (METRIC == MANHATTAN) {
+                    S.tA[r][cc] = fabs(x - y);
+                } else {
+                    S.tA[r][cc] = x * y;
+                }
+            }
+            __syncthreads();
+            if (wave == 0 || (METRIC == COSINE && wave == 1)) {
+                if (lane < n_rows) {
+                    const double* t = (wave == 0) ? &S.tA[lane][0] : &S.tB[METRIC == COSINE ? lane : 0][0];
+                    uint32_t cc = 0;
+                    for (; cc + 8 <= cw; cc += 8) {  // 8 LDS reads in flight, then 8 adds in index order
+                        double v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = t[cc + u];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc += v[u];
+                    }
+                    for (; cc < cw; ++cc) acc += t[cc];
+                }
+            } else if (METRIC == COSINE && wave == 2) {
+                const double* t = &S.qq[p * RP_CH];
+                for (uint32_t cc = 0; cc < cw; ++cc) acc += t[cc];
+            }
+        }
+    }
+    __syncthreads();
+    if (METRIC == COSINE) {
+        if (wave == 1) S.b[lane] = acc;
+        if (wave == 2 && lane == 0) S.c = acc;
+        __syncthreads();
+        if (wave == 0) {
+            A.a = acc;
+            A.b = S.b[lane];
+            A.c = S.c;
+        }
+    } else if (wave == 0) {
+        A.a = acc;
+    }
+}
+
 // Upper bound B on the REFERENCE f64 score of any row whose f32 scan key is <= t, for in-domain data
 // (finite, |v| <= 2^40, row norms 0 or >= 2^-40).  u = 2^-24, n = padded dim, R = max row norm,
 // Q = |query|.  Derivation in DESIGN.md ("Exactness bound"); every u-term carries a 2x safety factor.
@@ -416,7 +565,8 @@ __global__ __launch_bounds__(1024) void k_merge_finalize(const Cand32* __restric
                                                          const double* __restrict__ q64,
                                                          const double* __restrict__ q_norms, uint32_t dim,
                                                          uint32_t ld, uint64_t n_rows, uint32_t k, double R,
-                                                         double in_extra, SearchResultBlock* __restrict__ out)
+                                                         double in_extra, SearchResultBlock* __restrict__ out,
+                                                         uint32_t seq)
 {
     // one workgroup per query of the batch
     partials += (size_t)blockIdx.x * list_stride_q;
@@ -425,8 +575,7 @@ __global__ __launch_bounds__(1024) void k_merge_finalize(const Cand32* __restric
     const double Q = q_norms[blockIdx.x];
     constexpr int NW = 16;
     __shared__ Cand32 sh_lists[NW * WAVE];
-    __shared__ double tile[KP][RESCORE_CH + 1];
-    __shared__ double qtile[RESCORE_CH];
+    __shared__ RescoreLds<METRIC> rs;
     __shared__ uint32_t sh_pos[KP];
     __shared__ float sh_key[KP];
     __shared__ double sh_score[KP];
@@ -455,7 +604,7 @@ __global__ __launch_bounds__(1024) void k_merge_finalize(const Cand32* __restric
 
     // phase 2: exact f64 rescoring of the candidates
     Acc64<METRIC> A;
-    rescore_rows<METRIC, 1024>(master, q64, dim, sh_pos, n_cand, tile, qtile, A);
+    rescore_rows_par<METRIC>(master, q64, dim, sh_pos, n_cand, rs, A);
 
     // phase 3: rank by (score desc, pos asc), bound check, emit
     if (wave == 0) {
@@ -499,6 +648,12 @@ __global__ __launch_bounds__(1024) void k_merge_finalize(const Cand32* __restric
             out->n_out = k_eff;
             out->flags = flags;
         }
+        if (seq) {
+            // the host spins on out->seq (pinned memory): every lane's stores of the block above are complete at
+            // system scope before the stamp leaves (wave 0 is the only writer of the block)
+            __threadfence_system();
+            if (lane == 0) __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -520,8 +675,7 @@ __global__ __launch_bounds__(1024) void k_merge_finalize_multi(const Cand32* __r
 {
     constexpr int NW = 16;
     __shared__ Cand32 sh_lists[NW * WAVE];
-    __shared__ double tile[KP][RESCORE_CH + 1];
-    __shared__ double qtile[RESCORE_CH];
+    __shared__ RescoreLds<METRIC> rs;
     __shared__ uint32_t sh_pos[KMULTI_PARTS * KP];
     __shared__ float sh_key[KMULTI_PARTS * KP];
     __shared__ double sh_score[KMULTI_PARTS * KP];
@@ -556,7 +710,7 @@ __global__ __launch_bounds__(1024) void k_merge_finalize_multi(const Cand32* __r
     // phase 2: exact f64 rescoring, 64 rows at a time through the same LDS tile
     for (int p = 0; p < n_parts; ++p) {
         Acc64<METRIC> A;
-        rescore_rows<METRIC, 1024>(master, q64, dim, sh_pos + p * KP, sh_ncand[p], tile, qtile, A);
+        rescore_rows_par<METRIC>(master, q64, dim, sh_pos + p * KP, sh_ncand[p], rs, A);
         if (wave == 0) sh_score[p * KP + lane] = lane < sh_ncand[p] ? A.score() : 0.0;
         __syncthreads();
     }
@@ -1160,14 +1314,22 @@ int scan_grid(uint64_t n, const ScanShape& sh, const void* kernel)
 }
 }  // namespace
 
+bool scan_takes_qarg(uint32_t ld)
+{
+    if ((ld & 3) || ld > (uint32_t)SCAN_QARG_FLOATS) return false;
+    return scan_shape(ld / 4).special;
+}
+
 hipError_t launch_scan(hipStream_t s, int metric, const float* slab, const float* inv_norm, const double* q64,
-                       uint64_t n, uint32_t dim, uint32_t ld, Cand32* partials, ScanPlan* plan)
+                       uint64_t n, uint32_t dim, uint32_t ld, Cand32* partials, ScanPlan* plan, const float* q32_host)
 {
     if (n == 0 || n >= 0xFFFFFFFFull || (ld & 3)) return hipErrorInvalidValue;
     const uint32_t ld4 = ld / 4;
     const ScanShape sh = scan_shape(ld4);
     const f32x4* slab4 = reinterpret_cast<const f32x4*>(slab);
     const uint32_t n32 = (uint32_t)n;
+    const bool qarg = q32_host != nullptr && sh.special && ld <= (uint32_t)SCAN_QARG_FLOATS;
+    if (!qarg && !q64) return hipErrorInvalidValue;
     int grid = 0;
     hipError_t rc = dispatch_metric(metric, [&](auto M) -> hipError_t {
         constexpr int MM = decltype(M)::value;
@@ -1175,10 +1337,22 @@ hipError_t launch_scan(hipStream_t s, int metric, const float* slab, const float
             bool launched = false;
 #define VL_TRY_VARIANT(G, VPL, U, BPC)                                                                          \
     if (!launched && sh.g == G && sh.vpl == VPL && sh.u == U) {                                             \
-        auto kern = k_scan<MM, G, VPL, U>;                                                                   \
-        grid = scan_grid(n, sh, reinterpret_cast<const void*>(kern));                                        \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, slab4, inv_norm, q64, dim, n32, partials);           \
-        launched = true;                                                                                     \
+        if constexpr (G * VPL * 4 <= SCAN_QARG_FLOATS) {                                                     \
+            if (qarg) {                                                                                      \
+                auto kern = k_scan<MM, G, VPL, U>;                                                           \
+                grid = scan_grid(n, sh, reinterpret_cast<const void*>(kern));                                \
+                ScanQArg qa;                                                                                 \
+                memcpy(qa.v, q32_host, (size_t)ld * sizeof(float));                                          \
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, slab4, inv_norm, n32, partials, qa);   \
+                launched = true;                                                                             \
+            }                                                                                                \
+        }                                                                                                    \
+        if (!launched) {                                                                                     \
+            auto kern = k_scan_q64<MM, G, VPL, U>;                                                           \
+            grid = scan_grid(n, sh, reinterpret_cast<const void*>(kern));                                    \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, slab4, inv_norm, q64, dim, n32, partials); \
+            launched = true;                                                                                 \
+        }                                                                                                    \
     }
             VL_SCAN_VARIANTS(VL_TRY_VARIANT)
 #undef VL_TRY_VARIANT
@@ -1291,15 +1465,16 @@ const C* reduce_lists(hipStream_t s, const C* lists, int* n_lists, size_t* strid
 hipError_t launch_merge_finalize(hipStream_t s, int metric, Cand32* partials, int n_lists, int nq,
                                  const double* master, const double* q64, const double* q_norms, uint32_t dim,
                                  uint64_t n_rows, uint32_t k, double max_row_norm, SearchResultBlock* out,
-                                 double in_extra)
+                                 double in_extra, uint32_t seq)
 {
+    if (seq && nq != 1) return hipErrorInvalidValue;
     const uint32_t ld = (dim + 3u) & ~3u;
     size_t stride = (size_t)n_lists * KP;
     const Cand32* lists = reduce_lists<float, Cand32>(s, partials, &n_lists, &stride, nq, partials + PARTIALS32_LISTS * KP);
     return dispatch_metric(metric, [&](auto M) -> hipError_t {
         constexpr int MM = decltype(M)::value;
         hipLaunchKernelGGL((k_merge_finalize<MM>), dim3(nq), dim3(1024), 0, s, lists, n_lists, stride, master, q64,
-                           q_norms, dim, ld, n_rows, k, max_row_norm, in_extra, out);
+                           q_norms, dim, ld, n_rows, k, max_row_norm, in_extra, out, seq);
         return hipGetLastError();
     });
 }

@@ -36,6 +36,10 @@ struct SearchResultBlock {
     uint32_t flags;  // RESULT_* bits
     uint32_t pos[KP];
     double score[KP];
+    // completion stamp of a single search: written LAST (system-scope release) by the finalize kernel when the
+    // caller passed a non-zero `seq`; the host waits on it instead of on the stream (flat_index.cpp, wait_result)
+    uint32_t seq;
+    uint32_t pad;
 };
 constexpr uint32_t RESULT_NEEDS_EXACT = 1u;  // bound check failed / tie at the cut: redo on the exact path
 constexpr uint32_t RESULT_HAS_NAN = 2u;      // some score is NaN
@@ -76,8 +80,15 @@ constexpr size_t PARTIALS32_ENTRIES = (PARTIALS32_LISTS + 2 * (size_t)SCAN_BATCH
 constexpr size_t PARTIALS64_ENTRIES = (size_t)(SELECT_MAX_GRID + 128) * KP;
 
 // K1: f32 slab scan -> per-workgroup top-KP partial lists.
+// Two ways to hand over the query.  q32_host != nullptr (and scan_takes_qarg(ld)): the f32 query, zero padded to
+// `ld` floats, rounded from the f64 query to nearest even, is copied into the kernel arguments -- nothing has to
+// be on the device before the launch.  Otherwise q64 is the f64 query in device memory and each lane rounds its
+// slice itself.  Both forms produce the same keys.
+constexpr int SCAN_QARG_FLOATS = 768;
+bool scan_takes_qarg(uint32_t ld);
 hipError_t launch_scan(hipStream_t s, int metric, const float* slab, const float* inv_norm, const double* q64,
-                       uint64_t n, uint32_t dim, uint32_t ld, Cand32* partials, ScanPlan* plan);
+                       uint64_t n, uint32_t dim, uint32_t ld, Cand32* partials, ScanPlan* plan,
+                       const float* q32_host = nullptr);
 
 // `out` may be pinned host memory (the result block is written once, by one wave).
 // K2: merge partial lists -> top-KP, rescore them in reference f64 arithmetic from the master
@@ -90,10 +101,13 @@ constexpr int KMULTI_MAX = 220;
 hipError_t launch_merge_finalize_multi(hipStream_t s, int metric, Cand32* partials, int n_lists_total, int n_parts,
                                        const double* master, const double* q64, const double* q_norm, uint32_t dim,
                                        uint64_t n_rows, uint32_t k, double max_row_norm, SearchResultBlock* out);
+// q64 / q_norms may be device memory or device-visible pinned host memory (a single search reads its 3 KB query
+// straight from the pinned staging block: one workgroup, one PCIe round trip hidden behind the list merge).
+// seq != 0 (nq == 1 only): out->seq = seq is stored last, system-scope release, after the result block.
 hipError_t launch_merge_finalize(hipStream_t s, int metric, Cand32* partials, int n_lists, int nq,
                                  const double* master, const double* q64, const double* q_norms, uint32_t dim,
                                  uint64_t n_rows, uint32_t k, double max_row_norm, SearchResultBlock* out,
-                                 double in_extra = 0.0);
+                                 double in_extra = 0.0, uint32_t seq = 0);
 
 // K3: one slab pass for nq <= SCAN_BATCH_QB queries (q64 is [nq, dim]); lists are written query-major.
 bool scan_batch_supported(uint32_t ld);
