@@ -28,8 +28,17 @@ come from independent generators: no block depends on --steps/--warmup (plan_que
 
 Multi-GPU (`--gpus N`): the flat index is REPLICATED (each rank holds the full corpus) and ranks
 answer disjoint query streams -- no data-path collective; value = all ranks' queries / max time
-(weak scaling).  The row-sharded batched mode with an RCCL all-gather (config 3) is
-`tools/bench_sharded.py` over the C ABI's vl_shard_* entry points, not this headline line.
+(weak scaling).
+
+After the published timed region (never inside `value`) the same run measures the other BASELINE.json
+configurations, each with its own `roofline` object under `config.other_configs`:
+  N = 1   c2 (1 M x 384 single query, HBM), c5 (4096-query batch on the resident corpus, MFMA), c3_shard (one
+          rank's 1.25 M x 768 shard of config 3 through vl_shard_search_batch over a world-1 RCCL communicator,
+          HIP events around the all-gather and the merge), c4_hnsw (build, recall@10, QPS at ef 10 / 32 / 128
+          on embedding-like AND on i.i.d. gaussian rows), plus `value_sustained` (the headline search kept up
+          for 10 s) and one reference-faithful CPU query at full size (`cpu_baseline.full_size_check`).
+  N > 1   c3_row_sharded: config 3 at its own size -- 10 M x 768 rows cut into N contiguous shards, 1024
+          Euclidean queries per batch, ONE ncclAllGather per batch inside the library, device merge.
 """
 from __future__ import annotations
 
@@ -74,6 +83,19 @@ def parse_args(argv=None):
     p.add_argument("--cpu-queries", type=int, default=32)
     p.add_argument("--cpu-budget-s", type=float, default=30.0, help="stop the CPU baseline after this much CPU time")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    # the other BASELINE.json configurations, run after the published timed region (config.other_configs)
+    p.add_argument("--sustained-s", type=float, default=10.0, help="value_sustained: keep searching this long (>= 4000 queries at full size)")
+    p.add_argument("--c2-rows", type=int, default=1_000_000)
+    p.add_argument("--c5-queries", type=int, default=4096)
+    p.add_argument("--c3-rows", type=int, default=10_000_000, help="config 3's corpus; N = 1 times ONE shard of c3-shards")
+    p.add_argument("--c3-shards", type=int, default=8)
+    p.add_argument("--c3-dim", type=int, default=768)
+    p.add_argument("--c3-batch", type=int, default=1024)
+    p.add_argument("--c4-rows", type=int, default=1_000_000)
+    p.add_argument("--c4-queries", type=int, default=1000)
+    p.add_argument("--block-cap-s", type=float, default=60.0, help="soft cap per later block: steps still to run are skipped")
+    p.add_argument("--no-other-configs", action="store_true")
+    p.add_argument("--no-full-size-cpu-check", action="store_true")
     p.add_argument("--no-checks", action="store_true")
     p.add_argument("--inline", action="store_true", help="be the (single) rank in this process: no supervisor")
     p.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
@@ -306,6 +328,227 @@ def step_rates(stamps, t_start: float) -> dict:
     return out
 
 
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md (AMD's 2:1-sparsity headline figure is not used)
+
+
+def gen_unit_rows(torch, dev, n, dim, seed, latent_basis=None, noise=0.05):
+    """n unit rows on the device: i.i.d. N(0,1) (what src/embeddings.rs:173-179 leaves behind for
+    uninformative text), or rows of low intrinsic dimension z A + noise (embedding-like) when a basis is given."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    if latent_basis is None:
+        x = torch.randn((n, dim), dtype=torch.float64, device=dev, generator=g)
+    else:
+        x = torch.randn((n, latent_basis.shape[0]), dtype=torch.float64, device=dev, generator=g) @ latent_basis
+        x += noise * torch.randn((n, dim), dtype=torch.float64, device=dev, generator=g)
+    x /= torch.linalg.vector_norm(x, dim=1, keepdim=True)
+    return x
+
+
+def digest64(*arrays) -> int:
+    d = 0
+    for a in arrays:
+        d ^= int(np.bitwise_xor.reduce(np.ascontiguousarray(a).reshape(-1).view(np.int64)))
+    return d
+
+
+def c3_rows_for(rank: int, world: int, total: int, shards_at_n1: int):
+    """Config 3's row range of this rank.  world > 1: the corpus cut into `world` contiguous ranges.  world == 1: the
+    FIRST of `shards_at_n1` ranges -- one GPU times one rank's shard of the 8-GPU configuration."""
+    parts = world if world > 1 else max(1, shards_at_n1)
+    base, rem = divmod(total, parts)
+    starts = [0]
+    for r in range(parts):
+        starts.append(starts[-1] + base + (1 if r < rem else 0))
+    r = rank if world > 1 else 0
+    return starts[r], starts[r + 1], (total if world > 1 else starts[1])
+
+
+def run_c3(V, torch, dist, args, dev, dev_index, rank, world, rehearse, k, cap_s):
+    """BASELINE config 3 (flat L2, dim 768, 1024-query batches, rows sharded over the ranks): every rank answers the
+    batch on its own rows with the single-GPU pipeline, ONE ncclAllGather inside libvectorlite_amd.so
+    (vl_shard_search_batch) exchanges the per-shard top-k, a device kernel merges.  Collective: every rank calls it."""
+    from vectorlite_amd.sharded import Comm, ShardedFlatIndex
+    t_block = time.perf_counter()
+    dim, nq, metric = args.c3_dim, args.c3_batch, 1
+    lo, hi, corpus = c3_rows_for(rank, world, args.c3_rows, args.c3_shards)
+    shard = V.FlatIndex(dim, device=dev_index)
+    shard.reserve(hi - lo)
+    pos = lo
+    while pos < hi:
+        c = min(250_000, hi - pos)
+        x = gen_unit_rows(torch, dev, c, dim, 424242 + pos)  # a function of the global row range
+        shard.add_rows(ids_for(pos, c), x, validate=False)
+        pos += c
+        del x
+    Qs = unit_queries(2468, nq, dim)  # the same batch on every rank
+    comm = None
+    if rehearse:  # ranks share one card and RCCL refuses that: the records travel by gloo, the merge is the same kernel
+        sh = ShardedFlatIndex(shard, transport="torch")
+    elif world > 1:
+        comm = Comm.from_torch_distributed(device=dev_index)
+        sh = ShardedFlatIndex(shard, comm=comm)
+    else:
+        comm = Comm(Comm.unique_id(), 1, 0, dev_index)  # a world of one: the same RCCL calls, no peer
+        sh = ShardedFlatIndex(shard, comm=comm)
+    assert (sh.offset, sh.total) == (lo if world > 1 else 0, corpus), (sh.offset, sh.total, lo, corpus)
+    sh.search_batch(Qs[: min(nq, 128)], k, metric)  # bf16 slab, scratch, exchange buffers
+    sh.search_batch(Qs, k, metric)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    shard.profile_read()
+    shard.profile_enable(True)
+    if comm is not None:
+        comm.profile_read()
+        comm.profile_enable(True)
+    steps = 0
+    ts = time.perf_counter()
+    for _ in range(5):
+        si, ss, sn, sp = sh.search_batch(Qs, k, metric, with_positions=True)
+        steps += 1
+        if world == 1 and time.perf_counter() - t_block > cap_s:
+            break
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - ts) / steps
+    shard.profile_enable(False)
+    n_pass, filt_ms, _ = shard.profile_read()
+    prof = comm.profile_read() if comm is not None else None
+    if comm is not None:
+        comm.profile_enable(False)
+    same, own_ok, n_own = True, 0, 4
+    if dist is not None:
+        dig = torch.tensor([digest64(si), digest64(ss)], dtype=torch.int64, device="cpu" if rehearse else dev)
+        lo_d, hi_d = dig.clone(), dig.clone()
+        dist.all_reduce(lo_d, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_d, op=dist.ReduceOp.MAX)
+        same = bool((lo_d == hi_d).all().item())
+        tm = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dt = float(tm.item())
+    for qi in range(n_own):  # this rank's rows in the global answer are what its own single search() returns for them
+        li, ls = shard.search_arrays(Qs[qi], k, metric)
+        mine = [(int(i), float(sc)) for i, sc, pp in zip(si[qi], ss[qi], sp[qi]) if sh.offset <= int(pp) < sh.offset + (hi - lo)]
+        own_ok += int(mine == list(zip(li.tolist(), ls.tolist()))[: len(mine)])
+    if comm is not None:
+        comm.close()
+    rows_rank = hi - lo
+    flops_rank = 2.0 * nq * rows_rank * dim
+    filt = (filt_ms / steps) * 1e-3 if n_pass else 0.0
+    out = {
+        "workload": (f"flat euclidean batched search, corpus {corpus} x {dim}, {nq} queries per batch, k={k}, "
+                     f"{world} row shard(s) of {rows_rank} rows" +
+                     ("" if world > 1 else f" (one rank's shard of the {args.c3_shards}-GPU configuration, world-1 RCCL)")),
+        "n_gpus": world, "rows_per_rank": rows_rank, "queries": nq, "dim": dim,
+        "value": round(nq / dt, 1), "unit": "queries/s", "ms_per_batch": round(dt * 1e3, 3), "batches_timed": steps,
+        "transport": ("gloo records + device merge (rehearsal on one card)" if rehearse else
+                      "RCCL: one ncclAllGather per batch inside the library (vl_shard_search_batch), device merge"),
+        "collective_bytes_per_rank": 8 * (4 + nq + 3 * nq * min(k, rows_rank)),
+        "identical_on_every_rank": same, "own_rows_match_single_search": f"{own_ok}/{n_own}",
+        "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS,
+                     "kernel": "k_mfma_rows (sampling pass + pass-1 stages + thresholds / candidate select), per GPU",
+                     "flops_per_batch_per_gpu": flops_rank,
+                     "achieved": round(flops_rank / filt / 1e12, 1) if filt > 0 else None,
+                     "frac": round(flops_rank / filt / 1e12 / MFMA_PEAK_TFLOPS, 4) if filt > 0 else None,
+                     "filter_kernels_ms_per_batch": round(filt * 1e3, 3),
+                     "whole_call": {"achieved": round(flops_rank / dt / 1e12, 1),
+                                    "frac": round(flops_rank / dt / 1e12 / MFMA_PEAK_TFLOPS, 4)},
+                     "traffic": None},
+    }
+    if prof and prof["calls"]:
+        c = prof["calls"]
+        out["exchange_ms_per_batch"] = {"local_search_host_clock": round(prof["local_ms"] / c, 3),
+                                        "record_h2d": round(prof["h2d_ms"] / c, 4),
+                                        "ncclAllGather": round(prof["allgather_ms"] / c, 4),
+                                        "merge_kernel_and_d2h": round(prof["merge_ms"] / c, 4),
+                                        "note": "HIP events on the exchange stream (vl_comm_profile_read), rank 0"}
+    del sh, shard
+    torch.cuda.empty_cache()
+    return out
+
+
+def run_c4(V, torch, args, dev, dev_index, k, cap_s, log_fn):
+    """BASELINE config 4 (HNSW, default profile M 16 / M0 32, cosine, dim of the run): build on the GPU, recall@10 against
+    the exhaustive order, batched QPS and distance evaluations per query at ef 10 (the reference's ef = min(k, len),
+    src/index/hnsw.rs:437), 32 and 128 -- on embedding-like rows (latent dimension 16) AND on SURVEY 8(d)'s i.i.d.
+    gaussian unit rows.  The walk is this repository's own (crate hnsw 0.11.0 is not in the reference tree): parity
+    with the crate's walk is UNPINNED, the numbers are recall, not parity."""
+    t_block = time.perf_counter()
+    n, dim, nq = args.c4_rows, args.dim, args.c4_queries
+    res = {"workload": f"HNSW cosine, N={n}, dim={dim}, M=16 M0=32 ef_construction=128, {nq}-query batches, k={k}",
+           "parity": "unpinned (own walk; the crate's is not in the reference tree)", "data": {}}
+    for name, latent in (("latent16", 16), ("iid_gaussian", 0)):
+        if time.perf_counter() - t_block > cap_s:
+            res["data"][name] = {"skipped": "block time cap"}
+            continue
+        g = torch.Generator(device=dev)
+        g.manual_seed(99 + latent)
+        A = torch.randn((latent, dim), dtype=torch.float64, device=dev, generator=g) if latent else None
+        flat = V.FlatIndex(dim, device=dev_index)
+        flat.reserve(n)
+        hn = V.HNSWIndex(dim, 0, device=dev_index)
+        t_build = 0.0
+        done = 0
+        while done < n:
+            c = min(250_000, n - done)
+            x = gen_unit_rows(torch, dev, c, dim, 31337 + done + latent, A)
+            ids = np.arange(done, done + c, dtype=np.uint64)
+            flat.add_rows(ids, x, validate=False)
+            tb = time.perf_counter()
+            hn.add_rows(ids, x)
+            t_build += time.perf_counter() - tb
+            done += c
+            del x
+        rng = np.random.default_rng(4321 + latent)
+        if A is None:
+            Q = rng.standard_normal((nq, dim))
+        else:
+            Q = rng.standard_normal((nq, latent)) @ A.cpu().numpy() + 0.05 * rng.standard_normal((nq, dim))
+        Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+        ti, _, _ = flat.search_batch(Q, k, 0)  # exhaustive f64 order
+        # the graph only sees the reference's quantised u64 distances (src/index/hnsw.rs:113-174): recall is also
+        # counted against THAT order (ties at the k-th distance accepted), on a subset
+        nchk = min(nq, 32)
+        allpos = np.arange(n, dtype=np.uint64)
+        D = [flat.hnsw_distances(Q[i], allpos, 0) for i in range(nchk)]
+        kth = [np.partition(d, k - 1)[k - 1] for d in D]
+        per_ef = {}
+        for ef in (10, 32, 128):
+            strict = ef == 10
+            hn.set_min_beam(0 if strict else 32)
+            hn.search_batch(Q[:8], k, 0, ef=(0 if strict else ef))
+            q0, e0 = hn.walk_stats()
+            tq = time.perf_counter()
+            hi_, hs_, hnn = hn.search_batch(Q, k, 0, ef=(0 if strict else ef))
+            dtq = time.perf_counter() - tq
+            q1, e1 = hn.walk_stats()
+            evq = (e1 - e0) / max(q1 - q0, 1)
+            rec = float(np.mean([len(set(hi_[i, :int(hnn[i])].tolist()) & set(ti[i].tolist())) / float(k) for i in range(nq)]))
+            recq = float(np.mean([sum(1 for x in hi_[i, :int(hnn[i])] if D[i][int(x)] <= kth[i]) / float(k) for i in range(nchk)]))
+            row_bytes = (evq - max(ef, k)) * dim * 4 + max(ef, k) * dim * 8
+            gbps = (nq / dtq) * row_bytes / 1e9
+            per_ef[f"ef{ef}"] = {"recall_at_10_vs_exact_f64_order": round(rec, 4), "recall_at_10_vs_u64_distance_order": round(recq, 4),
+                                "queries_per_s": round(nq / dtq, 1), "distance_evals_per_query": round(evq, 1),
+                                "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": round(gbps, 1),
+                                             "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+                                             "note": "random 1.5-3 KB row reads of a latency-bound walk: rows read x row bytes / time"},
+                                "beam": "strict reference rule ef = min(k, len)" if strict else f"ef = {ef}"}
+        # a lone query at the reference's strict beam
+        hn.set_min_beam(0)
+        lat = []
+        for i in range(20):
+            tl = time.perf_counter()
+            hn.search_arrays(Q[i % nq], k, 0)
+            lat.append(time.perf_counter() - tl)
+        res["data"][name] = {"build_s": round(t_build, 2), "inserts_per_s": round(n / t_build, 0),
+                             "single_query_ms_strict_beam": round(float(np.median(lat)) * 1e3, 3), **per_ef}
+        log_fn(f"[bench] config 4 / {name}: build {t_build:.1f}s, " + ", ".join(f"{e}: {v['recall_at_10_vs_exact_f64_order']:.3f} @ {v['queries_per_s']:.0f} q/s" for e, v in per_ef.items()))
+        del flat, hn, A
+        torch.cuda.empty_cache()
+    return res
+
+
 def run_rank(args) -> int:
     # ONE JSON line on stdout means nothing else may land there: RCCL prints its version banner to STDOUT when
     # the first communicator is made (seen with torch's nccl backend and with vl_comm_create).  Everything this
@@ -366,10 +609,7 @@ def run_rank(args) -> int:
     ci = 0
     while done < n:
         c = min(args.chunk, n - done)
-        g = torch.Generator(device=dev)
-        g.manual_seed(1234 + ci)
-        x = torch.randn((c, dim), dtype=torch.float64, device=dev, generator=g)
-        x /= torch.linalg.vector_norm(x, dim=1, keepdim=True)
+        x = gen_unit_rows(torch, dev, c, dim, 1234 + ci)
         idx.add_rows(ids_for(done, c), x, validate=False)
         if want_cpu and done < n_sample:
             take = min(c, n_sample - done)
@@ -424,65 +664,22 @@ def run_rank(args) -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t.item())
 
-    def sharded_check():
-        """Every rank, after the timed region (N > 1 only; informational, never part of `value`): the row-sharded
-        batched search of config 3's kind on small shards -- each rank scans its own rows, ONE ncclAllGather inside
-        libvectorlite_amd.so (vl_shard_search_batch), device merge -- and the ranks compare digests of the answer."""
-        from vectorlite_amd.sharded import Comm, ShardedFlatIndex
-        rows_per, nqs = 200_000, 256
-        shard = V.FlatIndex(dim, device=dev_index)
-        g = torch.Generator(device=dev)
-        g.manual_seed(777 + rank)
-        x = torch.randn((rows_per, dim), dtype=torch.float64, device=dev, generator=g)
-        x /= torch.linalg.vector_norm(x, dim=1, keepdim=True)
-        shard.add_rows(ids_for(rank * rows_per, rows_per), x, validate=False)
-        del x
-        Qs = unit_queries(2468, nqs, dim)  # the same batch on every rank
-        comm = None
-        if rehearse:  # ranks share one card and RCCL refuses that: the records travel by gloo, the merge is the same kernel
-            sh = ShardedFlatIndex(shard, transport="torch")
-        else:
-            comm = Comm.from_torch_distributed(device=dev_index)
-            sh = ShardedFlatIndex(shard, comm=comm)
-        assert (sh.offset, sh.total) == (rank * rows_per, world * rows_per)
-        sh.search_batch(Qs, k, metric)
-        barrier()
-        ts = time.perf_counter()
-        for _ in range(3):
-            si, ss, sn, sp = sh.search_batch(Qs, k, metric, with_positions=True)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - ts) / 3
-        dig = torch.tensor([int(np.bitwise_xor.reduce(np.ascontiguousarray(si).reshape(-1).view(np.int64))),
-                            int(np.bitwise_xor.reduce(np.ascontiguousarray(ss).reshape(-1).view(np.int64)))],
-                           dtype=torch.int64, device="cpu" if rehearse else dev)
-        lo, hi = dig.clone(), dig.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        same = bool((lo == hi).all().item())
-        own_ok = 0
-        for qi in range(4):  # this rank's rows in the global answer are what its own single search() returns for them
-            li, ls = shard.search_arrays(Qs[qi], k, metric)
-            mine = [(int(i), float(sc)) for i, sc, pp in zip(si[qi], ss[qi], sp[qi]) if rank * rows_per <= int(pp) < (rank + 1) * rows_per]
-            own_ok += int(mine == list(zip(li.tolist(), ls.tolist()))[: len(mine)])
-        tm = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        if comm is not None:
-            comm.close()
-        return {"transport": "gloo records + device merge (rehearsal on one card)" if rehearse else "RCCL: one ncclAllGather per batch inside the library (vl_shard_search_batch)",
-                "shards": world, "rows_per_shard": rows_per, "queries": nqs, "ms_per_batch": round(float(tm.item()) * 1e3, 3),
-                "identical_on_every_rank": same, "own_rows_match_single_search": f"{own_ok}/4"}
+    run_sharded = use_dist and world > 1 and not args.no_checks and not args.no_other_configs
+    STUCK_S = 420.0  # a collective that never returns: give up, non-zero (a rank that touched the GPU never exits 0 on a hang)
 
-    run_sharded = use_dist and world > 1 and not args.no_checks
+    def c3_all_ranks():
+        return run_c3(V, torch, dist, args, dev, dev_index, rank, world, rehearse, k, args.block_cap_s)
+
     if rank != 0:
         dist.barrier()  # rank 0 has published the line
         if run_sharded:
-            wd = threading.Timer(120.0, lambda: os._exit(0))  # never outlive a stuck collective
+            wd = threading.Timer(STUCK_S, lambda: os._exit(3))
             wd.daemon = True
             wd.start()
             try:
-                sharded_check()
+                c3_all_ranks()
             except BaseException as e:  # noqa: BLE001
-                log(f"[bench] rank {rank}: row-sharded check failed: {type(e).__name__}: {e}")
+                log(f"[bench] rank {rank}: config 3 (row-sharded) failed: {type(e).__name__}: {e}")
             wd.cancel()
         dist.destroy_process_group()
         return 0
@@ -496,10 +693,13 @@ def run_rank(args) -> int:
     # correction; profiles/traffic.json).  PMC cannot be collected from inside this process, so the
     # figure is attached only when it was measured on exactly this workload.
     traffic = None
+    scan_used = idx.last_scan()
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             tj = json.load(f)["k_scan"]
-        if tj["workload"] == {"rows": n, "dim": dim, "metric": args.metric}:
+        # ... and by exactly this kernel: the instantiation and grid the PMC pass saw (a changed k_scan drops the figure)
+        if (tj["workload"] == {"rows": n, "dim": dim, "metric": args.metric} and tj.get("variant") == scan_used["variant"]
+                and tj.get("grid") == scan_used["grid"] and tj.get("query_in_kernarg") == scan_used["query_in_kernarg"]):
             traffic = tj["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
@@ -533,6 +733,7 @@ def run_rank(args) -> int:
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": traffic,
             "kernel": "k_scan",
+            "kernel_variant": scan_used,
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_launch_ms": round(avg_scan_ms, 4),
             "launches_timed": n_launch,
@@ -569,17 +770,19 @@ def run_rank(args) -> int:
 
     extras = world == 1 and not args.no_checks  # N>1: every rank leaves together, nothing runs on rank 0 alone
 
+    other = out["config"].setdefault("other_configs", {})
+
     if run_sharded:
         def on_stuck():  # a collective that never returns must not take the measured line with it
-            errors.append({"block": "row_sharded_check", "error": "no answer within 120 s: abandoned"})
+            errors.append({"block": "c3_row_sharded", "error": f"no answer within {STUCK_S:g} s: abandoned"})
             publish()
             if not args.result_file:
                 os.write(real_stdout, (json.dumps(out) + "\n").encode())
-            os._exit(0)
-        wd = threading.Timer(120.0, on_stuck)
+            os._exit(3)
+        wd = threading.Timer(STUCK_S, on_stuck)
         wd.daemon = True
         wd.start()
-        block("row_sharded_check", lambda: out["config"].__setitem__("row_sharded_check", sharded_check()))
+        block("c3_row_sharded", lambda: other.__setitem__("c3_row_sharded", c3_all_ranks()))
         wd.cancel()
 
     # ---- CPU baseline: the oracle (reference-faithful restatement), bounded sample ---------------
@@ -689,10 +892,181 @@ def run_rank(args) -> int:
                     "rescoring and bound check, fall back to the f32 scan when not certified",
         }
 
+    # ---- sustained rate: the same serial searches for --sustained-s seconds (thousands of steps, not a 20-step burst) ----
+    def sustained_block():
+        Qs = unit_queries(777, 512, dim)
+        idx.profile_read()
+        idx.profile_enable(True)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        cnt = 0
+        while True:
+            idx.search_arrays(Qs[cnt % 512], k, metric)
+            cnt += 1
+            if (cnt & 63) == 0 and time.perf_counter() - ts >= args.sustained_s:
+                break
+        torch.cuda.synchronize()
+        el = time.perf_counter() - ts
+        idx.profile_enable(False)
+        nl, ms_s, _ = idx.profile_read()
+        out["value_sustained"] = {"value": round(cnt / el, 3), "unit": "queries/s", "queries": cnt, "seconds": round(el, 2),
+                                  "ms_per_step": round(el / cnt * 1e3, 4),
+                                  "k_scan_avg_launch_ms": round(ms_s / max(nl, 1), 4),
+                                  "k_scan_frac_of_hbm_peak": round(alg_bytes / (ms_s / max(nl, 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if nl else None}
+
+    # ---- BASELINE config 2: the same search on the first --c2-rows rows (1 M): the scan no longer hides the fixed cost ----
+    def c2_block():
+        rows2 = min(args.c2_rows, n)
+        sub = V.FlatIndex(dim, device=dev_index)
+        sub.reserve(rows2)
+        d2, ci2 = 0, 0
+        while d2 < rows2:  # the first rows of the SAME corpus (same generator seeds as the build above)
+            c = min(args.chunk, n - d2)
+            x = gen_unit_rows(torch, dev, c, dim, 1234 + ci2)
+            take = min(c, rows2 - d2)
+            sub.add_rows(ids_for(d2, take), x[:take], validate=False)
+            d2 += take
+            ci2 += 1
+            del x
+        Q2 = unit_queries(2222, 64, dim)
+        for i in range(20):
+            sub.search_arrays(Q2[i], k, metric)
+        sub.profile_read()
+        sub.profile_enable(True)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        reps2 = 400
+        for i in range(reps2):
+            sub.search_arrays(Q2[i % 64], k, metric)
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t2
+        sub.profile_enable(False)
+        nl2, ms2, by2 = sub.profile_read()
+        same = 0
+        for i in range(4):  # the answer is a prefix-consistent function of the rows: the big index restricted to them
+            a_i, a_s = sub.search_arrays(Q2[i], k, metric)
+            sub.force_path(V.PATH_EXACT_SELECT)
+            b_i, b_s = sub.search_arrays(Q2[i], k, metric)
+            sub.force_path(0)
+            same += int(a_i.tolist() == b_i.tolist() and a_s.tolist() == b_s.tolist())
+        ach2 = (by2 / max(nl2, 1)) / (ms2 / max(nl2, 1) * 1e-3) / 1e9 if nl2 and ms2 > 0 else 0.0
+        other["c2"] = {"workload": f"flat {args.metric} single-query search, N={rows2}, dim={dim}, k={k}, 1 GPU",
+                       "value": round(reps2 / e2, 1), "unit": "queries/s", "ms_per_step": round(e2 / reps2 * 1e3, 4),
+                       "fast_vs_exact": f"{same}/4 queries bit-identical (ids and f64 scores)",
+                       "parity_vs_oracle": "the `parity` object of this line is measured on this row set" if want_cpu and rows2 == n_sample else None,
+                       "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": round(ach2, 1),
+                                    "frac": round(ach2 / HBM_PEAK_GBPS, 4), "kernel": "k_scan", "kernel_variant": sub.last_scan(),
+                                    "algorithmic_bytes_per_launch": rows2 * ld * 4, "avg_launch_ms": round(ms2 / max(nl2, 1), 4),
+                                    "launches_timed": nl2, "traffic": None,
+                                    "whole_call_frac": round(rows2 * ld * 4 / (e2 / reps2) / 1e9 / HBM_PEAK_GBPS, 4)}}
+
+    # ---- BASELINE config 5: 4096 queries in one search_batch on the resident corpus (bf16 MFMA filter + exact f64 finalize) ----
+    def c5_block():
+        nq5 = args.c5_queries
+        Q5 = unit_queries(5555, nq5, dim)
+        idx.search_batch(Q5[:64], k, metric)  # builds the fragment-major bf16 slab and the scratch
+        idx.search_batch(Q5, k, metric)
+        torch.cuda.synchronize()
+        idx.profile_read()
+        idx.profile_enable(True)
+        t5 = time.perf_counter()
+        reps5 = 3
+        for _ in range(reps5):
+            bi, bs, bn = idx.search_batch(Q5, k, metric)
+        w5 = (time.perf_counter() - t5) / reps5
+        idx.profile_enable(False)
+        n_pass, ms5, _ = idx.profile_read()
+        kern = ms5 / reps5 * 1e-3
+        flops = 2.0 * nq5 * n * dim
+        pick = np.linspace(0, nq5 - 1, 16).astype(int)
+        ok5 = 0
+        for qi in pick:
+            s_i, s_s = idx.search_arrays(Q5[qi], k, metric)
+            ok5 += int(bi[qi].tolist() == s_i.tolist() and bs[qi].tolist() == s_s.tolist())
+        other["c5"] = {"workload": f"batched flat {args.metric} search as a bf16 MFMA GEMM: Q={nq5}, N={n}, dim={dim}, k={k}, 1 GPU",
+                       "value": round(nq5 / w5, 1), "unit": "queries/s", "ms_per_batch": round(w5 * 1e3, 3),
+                       "launch_sequences_per_batch": n_pass // max(reps5, 1),
+                       "rows_identical_to_single_search": f"{ok5}/16 sampled (ids and f64 scores)",
+                       "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS,
+                                    "kernel": "k_mfma_rows (sampling pass + pass-1 stages + thresholds / candidate select)",
+                                    "flops_per_batch": flops, "achieved": round(flops / kern / 1e12, 1) if kern > 0 else None,
+                                    "frac": round(flops / kern / 1e12 / MFMA_PEAK_TFLOPS, 4) if kern > 0 else None,
+                                    "filter_kernels_ms_per_batch": round(kern * 1e3, 3),
+                                    "whole_call": {"achieved": round(flops / w5 / 1e12, 1), "frac": round(flops / w5 / 1e12 / MFMA_PEAK_TFLOPS, 4)},
+                                    "traffic": None}}
+
+    def c3_block():
+        other["c3_shard"] = run_c3(V, torch, None, args, dev, dev_index, 0, 1, False, k, args.block_cap_s)
+
+    def c4_block():
+        other["c4_hnsw"] = run_c4(V, torch, args, dev, dev_index, k, args.block_cap_s, log)
+
+    # ---- one reference-faithful CPU query at FULL size (SURVEY 8(d) "run d384 fully"): is the x N scaling above true? ----
+    def cpu_full_block():
+        need = n * dim * 8 * 1.25 + 6e9
+        avail = None
+        try:
+            for ln in open("/proc/meminfo"):
+                if ln.startswith("MemAvailable:"):
+                    avail = int(ln.split()[1]) * 1024
+            for pth in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+                if os.path.exists(pth):
+                    v = open(pth).read().strip()
+                    if v != "max":
+                        used = 0
+                        for up in ("/sys/fs/cgroup/memory.current", "/sys/fs/cgroup/memory/memory.usage_in_bytes"):
+                            if os.path.exists(up):
+                                used = int(open(up).read().strip())
+                        avail = min(avail, int(v) - used) if avail is not None else int(v) - used
+        except Exception:
+            pass
+        cb = out.setdefault("cpu_baseline", {})
+        if avail is None or avail < max(need, 48e9 if n >= 10_000_000 else 0):
+            cb["full_size_check"] = {"ran": False, "why": f"needs ~{need / 1e9:.0f} GB of host memory for {n} AoS f64 rows, "
+                                                          f"{'unknown' if avail is None else round(avail / 1e9, 1)} GB available"}
+            return
+        from oracle import oracle as O
+        O.build()
+        ref = O.FlatOracle(dim)
+        d3, ci3 = 0, 0
+        tb = time.perf_counter()
+        while d3 < n:
+            c = min(args.chunk, n - d3)
+            x = gen_unit_rows(torch, dev, c, dim, 1234 + ci3)  # the corpus of the timed region, chunk by chunk
+            ref.extend(ids_for(d3, c), x.cpu().numpy())
+            d3 += c
+            ci3 += 1
+            del x
+        build_s = time.perf_counter() - tb
+        nqf = 2
+        same = 0
+        tq = time.perf_counter()
+        ref_res = [ref.search(Qc[i], k, metric) for i in range(nqf)]
+        cpu_s = time.perf_counter() - tq
+        for i in range(nqf):
+            gi, gs = idx.search_arrays(Qc[i], k, metric)
+            same += int(gi.tolist() == ref_res[i][0].tolist() and gs.tolist() == ref_res[i][1].tolist())
+        del ref
+        full_qps = nqf / cpu_s
+        cb["full_size_check"] = {"ran": True, "rows": n, "queries": nqf, "seconds_per_query": round(cpu_s / nqf, 3),
+                                 "value": round(full_qps, 5), "unit": "queries/s",
+                                 "scaled_sample_value": cb.get("value"),
+                                 "scaled_over_full": round(cb["value"] / full_qps, 4) if cb.get("value") else None,
+                                 "gpu_answer_bit_identical": f"{same}/{nqf} (ids and f64 scores, N={n})",
+                                 "oracle_build_s": round(build_s, 1)}
+
     if extras:
+        block("value_sustained", sustained_block)
         block("fast_vs_exact_full_size", exact_block)
+        if not args.no_other_configs:
+            block("c2", c2_block)
+            block("c5", c5_block)
+            block("c3_shard", c3_block)
+            block("c4_hnsw", c4_block)
         block("d2d_copy_ceiling", d2d_block)
         block("bf16_first_filter", bf16_block)
+        if want_cpu and not args.no_full_size_cpu_check:
+            block("cpu_full_size_check", cpu_full_block)
 
     publish()
     if not args.result_file:

@@ -264,7 +264,11 @@ int vl_index_search_batch_embeddings_f32(const vl_index *h, const float *embeddi
  * top-k records, and a device kernel merges them by (score desc, GLOBAL position asc) -- the reference's stable
  * sort (src/index/flat.rs:116) applied to the whole corpus, so the answer is bit-identical to one index holding
  * every row.  All ranks must make the same calls with the same queries / k / metric; errors of any one shard
- * travel inside the exchange, so every rank returns the same status and nobody is left waiting.
+ * travel inside the exchange, so every rank returns the same status and nobody is left waiting.  That covers the
+ * local search (status in word 0 of the record) and the growth of the exchange buffers (a pre-flight status
+ * all-gather through buffers made at vl_comm_create, run by every rank exactly when the buffers have to grow); a
+ * device failure that leaves a rank no way to join a collective ends in ncclCommAbort on that rank -- its peers'
+ * collective fails instead of waiting -- and the communicator then refuses every later call (VL_ERR_DEVICE).
  *
  * vl_comm_unique_id: rank 0 makes the ncclUniqueId and hands the 128 bytes to the other ranks by whatever
  * channel the host has (the Rust server would use its own RPC; the Python harness broadcasts it with
@@ -276,6 +280,13 @@ int vl_comm_create(const uint8_t *id, int world, int rank, int device, vl_comm *
 void vl_comm_destroy(vl_comm *comm);
 int vl_comm_world(const vl_comm *comm);
 int vl_comm_rank(const vl_comm *comm);
+
+/* Where a batch's time goes on this rank, summed over the vl_shard_search_batch* calls since the last read: the
+ * local search (host clock) and, from HIP events on the exchange stream, the H2D copy of this rank's record, the
+ * ncclAllGather over xGMI, and the merge kernel + D2H of the answer.  Reading clears the totals. */
+int vl_comm_profile_enable(vl_comm *comm, int enable);
+int vl_comm_profile_read(vl_comm *comm, uint64_t *calls, double *local_ms, double *h2d_ms, double *allgather_ms,
+                         double *merge_ms);
 
 /* Collective: the ranks exchange (len, dimension) of their shards; each learns the global position of its
  * first row (*out_offset, rank order) and the total row count.  Call after building the shards and again
@@ -356,6 +367,11 @@ int vl_index_hnsw_walk_stats(const vl_index *h, uint64_t *queries, uint64_t *dis
 int vl_index_profile_enable(vl_index *h, int enable);
 int vl_index_profile_read(vl_index *h, uint64_t *n_scan_launches, double *scan_ms_total,
                           uint64_t *scan_bytes_total);
+
+/* Which instantiation of the f32 scan kernel answered the last single search on this handle: variant = G * 10000 +
+ * VPL * 100 + U of k_scan<metric, G, VPL, U> (negative: k_scan_generic's G), the number of workgroups it was launched
+ * on, and whether the query travelled in the kernel arguments.  bench.py ties its PMC traffic figure to these. */
+int vl_index_last_scan(const vl_index *h, int *variant, int *grid, int *query_in_kernarg);
 
 /* Library/version probe; also reports how many HIP devices are visible (0 -> no GPU). */
 int vl_runtime_info(int *n_devices, int *abi_version);

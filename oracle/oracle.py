@@ -65,6 +65,8 @@ def lib() -> C.CDLL:
         L.vlo_embed_f32.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_int, dp]
         L.vlo_flat_new.restype = C.c_void_p
         L.vlo_flat_new.argtypes = [C.c_size_t, u64p, dp, C.c_size_t]
+        L.vlo_flat_extend.restype = C.c_int
+        L.vlo_flat_extend.argtypes = [C.c_void_p, u64p, dp, C.c_size_t]
         L.vlo_flat_free.restype = None
         L.vlo_flat_free.argtypes = [C.c_void_p]
         L.vlo_flat_add.restype = C.c_int
@@ -162,6 +164,14 @@ class FlatOracle:
         if h and _lib is not None:
             _lib.vlo_flat_free(h)
             self._h = None
+
+    def extend(self, ids, values) -> None:
+        """More rows without validation (FlatIndex::new's data, appended chunk by chunk)."""
+        ids = np.ascontiguousarray(np.asarray(ids, dtype=np.uint64))
+        values = _f64(values)
+        assert values.size == ids.size * self.dim
+        if lib().vlo_flat_extend(self._h, _u64p(ids), _dp(values), ids.size) != OK:
+            raise MemoryError("vlo_flat_extend")
 
     def add(self, id: int, values) -> None:
         v = _f64(values)

@@ -265,6 +265,15 @@ vlo_flat *vlo_flat_new(size_t dim, const uint64_t *ids, const double *values, si
     return f;
 }
 
+/* More rows appended as FlatIndex::new would hold them (no validation, src/index/flat.rs:68-73): lets a caller build
+ * a corpus too large to stage twice in host memory chunk by chunk (bench.py's full-size CPU query). */
+int vlo_flat_extend(vlo_flat *f, const uint64_t *ids, const double *values, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        if (push_row(f, ids[i], values + i * f->dim, f->dim) != 0) return -1;
+    return VLO_OK;
+}
+
 void vlo_flat_free(vlo_flat *f)
 {
     if (!f) return;

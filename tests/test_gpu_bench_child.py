@@ -12,6 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
+# the rehearsal form of the other BASELINE configurations: the same code, small sizes
+SMALL_OTHER = ["--sustained-s", "0.3", "--c2-rows", "50000", "--c5-queries", "256", "--c3-rows", "160000", "--c3-batch", "128",
+               "--c4-rows", "20000", "--c4-queries", "64"]
+
 
 def _run(extra, timeout=600):
     env = dict(os.environ)
@@ -28,7 +32,7 @@ def _run(extra, timeout=600):
 @pytest.mark.parametrize("steps,warmup", [(3, 1), (1, 0)])
 def test_bench_child_process_prints_the_whole_contract_line(steps, warmup):
     out, err = _run(["--gpus", "1", "--rows", "200000", "--steps", str(steps), "--warmup", str(warmup),
-                     "--cpu-sample-rows", "20000", "--cpu-queries", "4"])
+                     "--cpu-sample-rows", "20000", "--cpu-queries", "4"] + SMALL_OTHER)
     assert "errors" not in out, out["errors"]
     assert out["metric"].startswith("flat-cosine QPS") and out["unit"] == "queries/s"
     assert out["n_gpus"] == 1 and out["steps"] == steps and out["warmup"] == warmup
@@ -51,6 +55,28 @@ def test_bench_child_process_prints_the_whole_contract_line(steps, warmup):
     assert out["config"]["search_paths_seen"] == [1]  # PATH_FAST: the f32 scan is what was timed
     assert out["config"]["prewarm_queries_untimed"] >= 10
     assert "value_first_5_steps" in out
+    # the other BASELINE configurations ride on the same line, each with its own roofline object
+    sus = out["value_sustained"]
+    assert sus["queries"] >= 64 and sus["value"] > 0 and sus["k_scan_avg_launch_ms"] > 0
+    oc = out["config"]["other_configs"]
+    assert set(oc) == {"c2", "c5", "c3_shard", "c4_hnsw"}
+    assert oc["c2"]["roofline"]["bound"] == "hbm" and 0 < oc["c2"]["roofline"]["frac"] < 1 and oc["c2"]["fast_vs_exact"].startswith("4/4")
+    assert oc["c5"]["roofline"]["bound"] == "mfma" and oc["c5"]["roofline"]["frac"] > 0
+    assert oc["c5"]["rows_identical_to_single_search"].startswith("16/16")
+    c3 = oc["c3_shard"]
+    assert c3["n_gpus"] == 1 and c3["rows_per_rank"] == 20000 and c3["roofline"]["bound"] == "mfma" and c3["roofline"]["frac"] > 0
+    assert c3["own_rows_match_single_search"] == "4/4" and c3["transport"].startswith("RCCL")
+    assert set(c3["exchange_ms_per_batch"]) >= {"ncclAllGather", "merge_kernel_and_d2h", "local_search_host_clock"}
+    c4 = oc["c4_hnsw"]
+    assert c4["parity"].startswith("unpinned") and set(c4["data"]) == {"latent16", "iid_gaussian"}
+    for dist_name in ("latent16", "iid_gaussian"):
+        d = c4["data"][dist_name]
+        for ef in ("ef10", "ef32", "ef128"):
+            assert 0.0 <= d[ef]["recall_at_10_vs_exact_f64_order"] <= 1.0 and d[ef]["roofline"]["frac"] >= 0
+        assert d["ef128"]["recall_at_10_vs_exact_f64_order"] >= d["ef10"]["recall_at_10_vs_exact_f64_order"] - 0.05
+    full = cb["full_size_check"]
+    assert full["ran"] is True and full["gpu_answer_bit_identical"].startswith("2/2")
+    assert rf["kernel_variant"]["query_in_kernarg"] == 1
 
 
 def test_bench_two_ranks_without_an_external_launcher():
@@ -58,7 +84,7 @@ def test_bench_two_ranks_without_an_external_launcher():
     env_before = os.environ.get("VL_BENCH_REHEARSE")
     os.environ["VL_BENCH_REHEARSE"] = "1"
     try:
-        out, err = _run(["--gpus", "2", "--rows", "100000", "--steps", "4", "--warmup", "1"])
+        out, err = _run(["--gpus", "2", "--rows", "100000", "--steps", "4", "--warmup", "1", "--c3-rows", "60000", "--c3-batch", "128"])
     finally:
         if env_before is None:
             os.environ.pop("VL_BENCH_REHEARSE", None)
@@ -69,6 +95,8 @@ def test_bench_two_ranks_without_an_external_launcher():
     assert out["value"] > 0 and out["roofline"]["launches_timed"] == 4
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
     # after the timed region the ranks also answer one row-sharded batch together (device merge; RCCL on real multi-GPU)
-    rs = out["config"]["row_sharded_check"]
-    assert rs["shards"] == 2 and rs["identical_on_every_rank"] is True and rs["own_rows_match_single_search"] == "4/4"
+    rs = out["config"]["other_configs"]["c3_row_sharded"]
+    assert rs["n_gpus"] == 2 and rs["rows_per_rank"] == 30000 and rs["dim"] == 768 and rs["queries"] == 128
+    assert rs["identical_on_every_rank"] is True and rs["own_rows_match_single_search"] == "4/4"
+    assert rs["roofline"]["bound"] == "mfma" and rs["roofline"]["whole_call"]["frac"] > 0
     assert "errors" not in out, out.get("errors")

@@ -472,6 +472,12 @@ class FlatIndex:
         _raise(self._L.vl_index_coalesce_stats(self._h, C.byref(b), C.byref(q)))
         return int(b.value), int(q.value)
 
+    def last_scan(self) -> Dict[str, int]:
+        """Which k_scan instantiation / grid answered the last single search (vl_index_last_scan)."""
+        v, g, q = C.c_int(0), C.c_int(0), C.c_int(0)
+        _raise(self._L.vl_index_last_scan(self._h, C.byref(v), C.byref(g), C.byref(q)))
+        return {"variant": int(v.value), "grid": int(g.value), "query_in_kernarg": int(q.value)}
+
     def profile_enable(self, on: bool) -> None:
         _raise(self._L.vl_index_profile_enable(self._h, 1 if on else 0))
 

@@ -375,6 +375,21 @@ void vl_comm_destroy(vl_comm* comm)
 int vl_comm_world(const vl_comm* comm) { return comm && comm->c ? comm->c->world() : 0; }
 int vl_comm_rank(const vl_comm* comm) { return comm && comm->c ? comm->c->rank() : -1; }
 
+int vl_comm_profile_enable(vl_comm* comm, int enable)
+{
+    if (!comm || !comm->c) return VL_ERR_INVALID_ARG;
+    comm->c->profile_enable(enable != 0);
+    return VL_OK;
+}
+
+int vl_comm_profile_read(vl_comm* comm, uint64_t* calls, double* local_ms, double* h2d_ms, double* allgather_ms,
+                         double* merge_ms)
+{
+    if (!comm || !comm->c) return VL_ERR_INVALID_ARG;
+    comm->c->profile_read(calls, local_ms, h2d_ms, allgather_ms, merge_ms);
+    return VL_OK;
+}
+
 int vl_shard_sync(const vl_index* shard, vl_comm* comm, uint64_t* out_offset, uint64_t* out_total)
 {
     return guarded([&]() -> int {
@@ -667,6 +682,13 @@ int vl_index_hnsw_walk_stats(const vl_index* h, uint64_t* queries, uint64_t* dis
 {
     if (!h || !h->hnsw) return VL_ERR_INVALID_ARG;
     h->hnsw->walk_stats(queries, distance_evals);
+    return VL_OK;
+}
+
+int vl_index_last_scan(const vl_index* h, int* variant, int* grid, int* query_in_kernarg)
+{
+    VL_FLAT_ONLY(h);
+    h->flat->last_scan(variant, grid, query_in_kernarg);
     return VL_OK;
 }
 

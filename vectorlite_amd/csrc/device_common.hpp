@@ -252,19 +252,48 @@ __device__ __forceinline__ void block_merge(TopList<K>& L, C* sh /* [NW][64] */)
     }
 }
 
-// Fold up to 4 consecutive sorted lists (global memory) into L with bitonic merges.
+// The same for a workgroup in which only waves [0, active) hold a list (the others' are empty): the tree spans the
+// next power of two of `active`, so 12 scan lists (3 waves) cost 2 levels, not 4.  `active` is workgroup-uniform.
 template <typename K, typename C>
-__device__ __forceinline__ void fold_lists4(TopList<K>& L, const C* __restrict__ lists, int first, int count)
+__device__ __forceinline__ void block_merge_n(TopList<K>& L, C* sh, int active)
 {
     const int lane = lane_id();
-    L.init();
-    C e[4];
+    const int wave = threadIdx.x >> 6;
+    int top = 1;
+    while (top < active) top <<= 1;
+    if (wave < top) {
+        sh[wave * WAVE + lane].key = L.key;
+        sh[wave * WAVE + lane].pos = L.pos;
+    }
+    __syncthreads();
+    for (int s = top / 2; s >= 1; s >>= 1) {
+        if (wave < s) {
+            const C o = sh[(wave + s) * WAVE + (WAVE - 1 - lane)];
+            L.merge_reversed(o.key, o.pos);
+            sh[wave * WAVE + lane].key = L.key;
+            sh[wave * WAVE + lane].pos = L.pos;
+        }
+        __syncthreads();
+    }
+}
+
+// Fold up to 4 consecutive sorted lists (global memory) into L with bitonic merges: the loads (all in flight
+// together) and the merges are separate steps so that a caller can issue other loads in between.
+template <typename C>
+__device__ __forceinline__ void fold_lists4_load(C (&e)[4], const C* __restrict__ lists, int first, int count)
+{
+    const int lane = lane_id();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {  // all loads in flight together
+    for (int i = 0; i < 4; ++i) {
         const int li = first + (i < count ? i : 0);
         const int slot = i == 0 ? lane : (KP - 1 - lane);
         if (count > 0) e[i] = lists[(size_t)li * KP + slot];
     }
+}
+template <typename K, typename C>
+__device__ __forceinline__ void fold_lists4_merge(TopList<K>& L, const C (&e)[4], int count)
+{
+    L.init();
     if (count > 0) {
         L.key = e[0].key;
         L.pos = e[0].pos;
@@ -274,6 +303,13 @@ __device__ __forceinline__ void fold_lists4(TopList<K>& L, const C* __restrict__
         if (i < count) L.merge_reversed(e[i].key, e[i].pos);
     L.thr_key = read_lane(L.key, WAVE - 1);
     L.thr_pos = read_lane(L.pos, WAVE - 1);
+}
+template <typename K, typename C>
+__device__ __forceinline__ void fold_lists4(TopList<K>& L, const C* __restrict__ lists, int first, int count)
+{
+    C e[4];
+    fold_lists4_load<C>(e, lists, first, count);
+    fold_lists4_merge<K, C>(L, e, count);
 }
 
 

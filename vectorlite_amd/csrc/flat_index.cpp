@@ -857,6 +857,9 @@ int GpuFlatIndex::search_locked(Workspace* ws, const double* query, uint64_t k_e
         if (prof) VL_HIP(hipEventRecord(ws->ev1, st));
         VL_HIP(launch_merge_finalize(st, metric, ws->d_partials, plan.grid, 1, d_master_, fq, fq + dim_, (uint32_t)dim_, n,
                                      (uint32_t)k_eff, max_row_norm_, ws->h_result, 0.0, seq));
+        last_scan_variant_.store(plan.variant, std::memory_order_relaxed);
+        last_scan_grid_.store(plan.grid, std::memory_order_relaxed);
+        last_scan_qarg_.store(qarg ? 1 : 0, std::memory_order_relaxed);
         VL_TRY(wait_result(ws, seq));
         if (prof) {
             float ms = 0.f;

@@ -156,6 +156,14 @@ public:
     void coalesce_stats(uint64_t* batches, uint64_t* queries) const { co_.stats(batches, queries); }
     void profile_enable(bool on);
     void profile_read(uint64_t* n, double* ms, uint64_t* bytes);
+    // which k_scan instantiation (G * 10000 + VPL * 100 + U; negative: the generic kernel's G), on how many workgroups,
+    // the last single f32 scan used, and whether its query travelled in the kernel arguments
+    void last_scan(int* variant, int* grid, int* qarg) const
+    {
+        if (variant) *variant = last_scan_variant_.load();
+        if (grid) *grid = last_scan_grid_.load();
+        if (qarg) *qarg = last_scan_qarg_.load();
+    }
     int device() const { return device_; }
 
 private:
@@ -232,6 +240,7 @@ private:
     static constexpr int SPIN_MAX_SEARCHERS = 2;
     static constexpr int SPIN_MAX_MS = 200;
     mutable std::atomic<int> active_searches_{0};
+    mutable std::atomic<int> last_scan_variant_{0}, last_scan_grid_{0}, last_scan_qarg_{0};
     mutable std::mutex prof_mu_;
     mutable uint64_t prof_n_ = 0;
     mutable double prof_ms_ = 0.0;

@@ -402,6 +402,20 @@ __device__ __forceinline__ void rescore_rows(const double* __restrict__ master, 
     }
 }
 
+#ifdef VL_DBG_STAMPS
+// diagnostic build only (tools/build_variant_k.sh): 100 MHz timestamps of the phases of one finalize launch
+__device__ unsigned long long vl_dbg_stamps[32];
+#define VL_STAMP(i)                                                                  \
+    do {                                                                             \
+        if (threadIdx.x == 0 && blockIdx.x == 0) {                                   \
+            vl_dbg_stamps[i] = __builtin_amdgcn_s_memrealtime();                     \
+            vl_dbg_stamps[16 + (i)] = __builtin_amdgcn_s_memtime(); /* shader clock */ \
+        }                                                                            \
+    } while (0)
+#else
+#define VL_STAMP(i) do {} while (0)
+#endif
+
 // The finalize kernels' rescoring (1024 threads): the same reference arithmetic with the serial part cut down to
 // what the reference makes serial.  `a += x * y` under -ffp-contract=off is t = fl(x * y); a = fl(a + t): the
 // products do not depend on the running sum, so ALL threads compute them while they move the rows through LDS
@@ -427,8 +441,10 @@ struct RescoreLds {
 template <int METRIC>
 __device__ __forceinline__ void rescore_rows_par(const double* __restrict__ master, const double* __restrict__ q64,
                                                  uint32_t dim, const uint32_t* sh_pos, int n_rows,
-                                                 RescoreLds<METRIC>& S, Acc64<METRIC>& A)
+                                                 RescoreLds<METRIC>& S, Acc64<METRIC>& A, double q_first)
 {
+    // q_first: q64[min(tid, dim - 1)] for tid < RP_BW, fetched by the caller at kernel entry (a single search reads
+    // its query from pinned host memory: that PCIe round trip then hides behind the list merge)
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1), wave = tid >> 6;
     A.init();
@@ -452,17 +468,19 @@ __device__ __forceinline__ void rescore_rows_par(const double* __restrict__ mast
                 pre[p][i] = master[(size_t)sh_pos[r] * dim + col];
             }
         }
-        double qv = 0.0;
-        if (tid < RP_BW) {
+        double qv = q_first;
+        if (g0 != 0 && tid < RP_BW) {
             const uint32_t col = g0 + (uint32_t)tid;
             qv = q64[col < dim ? col : dim - 1];
         }
+        VL_STAMP(4);
         __syncthreads();  // the previous block's qblk / tiles are consumed
         if (tid < RP_BW) {
             S.qblk[tid] = qv;
             if (METRIC == COSINE) S.qq[tid] = qv * qv;
         }
         __syncthreads();
+        VL_STAMP(5);
 #pragma unroll
         for (int p = 0; p < RP_NCH; ++p) {
             const uint32_t c0 = g0 + p * RP_CH;
@@ -491,12 +509,12 @@ __device__ __forceinline__ void rescore_rows_par(const double* __restrict__ mast
                 if (lane < n_rows) {
                     const double* t = (wave == 0) ? &S.tA[lane][0] : &S.tB[METRIC == COSINE ? lane : 0][0];
                     uint32_t cc = 0;
-                    for (; cc + 8 <= cw; cc += 8) {  // 8 LDS reads in flight, then 8 adds in index order
-                        double v[8];
+                    for (; cc + 16 <= cw; cc += 16) {  // 16 LDS reads in flight, then 16 adds in index order
+                        double v[16];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) v[u] = t[cc + u];
+                        for (int u = 0; u < 16; ++u) v[u] = t[cc + u];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) acc += v[u];
+                        for (int u = 0; u < 16; ++u) acc += v[u];
                     }
                     for (; cc < cw; ++cc) acc += t[cc];
                 }
@@ -504,8 +522,10 @@ __device__ __forceinline__ void rescore_rows_par(const double* __restrict__ mast
                 const double* t = &S.qq[p * RP_CH];
                 for (uint32_t cc = 0; cc < cw; ++cc) acc += t[cc];
             }
+            if (p == 0) VL_STAMP(6);
         }
     }
+    VL_STAMP(7);
     __syncthreads();
     if (METRIC == COSINE) {
         if (wave == 1) S.b[lane] = acc;
@@ -578,21 +598,29 @@ __global__ __launch_bounds__(1024) void k_merge_finalize(const Cand32* __restric
     __shared__ RescoreLds<METRIC> rs;
     __shared__ uint32_t sh_pos[KP];
     __shared__ float sh_key[KP];
-    __shared__ double sh_score[KP];
     __shared__ int sh_ncand;
 
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
 
-    // phase 1: n_lists <= 64 sorted lists: 16 waves x 4 bitonic folds, then a 4-level tree merge
+    VL_STAMP(0);
+    // phase 1: n_lists <= 64 sorted lists: up to 16 waves x 4 bitonic folds, then a tree merge over the waves that hold one
     TopList<float> L;
+    double q_first = 0.0;
     {
         const int first = wave * 4;
         int count = n_lists - first;
         count = count < 0 ? 0 : (count > 4 ? 4 : count);
-        fold_lists4<float, Cand32>(L, partials, first, count);
+        Cand32 e[4];
+        fold_lists4_load<Cand32>(e, partials, first, count);
+        // the query's first block is requested BEHIND the list loads (vector loads return in order: in front of
+        // them the wave would sit out the pinned-memory round trip before it can merge) and is consumed only in phase 2
+        if (threadIdx.x < RP_BW) q_first = q64[threadIdx.x < dim ? threadIdx.x : dim - 1];
+        fold_lists4_merge<float, Cand32>(L, e, count);
     }
-    block_merge<float, Cand32, NW>(L, sh_lists);
+    VL_STAMP(1);
+    block_merge_n<float, Cand32>(L, sh_lists, (n_lists + 3) / 4);
+    VL_STAMP(2);
     if (wave == 0) {
         sh_pos[lane] = L.pos;
         sh_key[lane] = L.key;
@@ -604,20 +632,23 @@ __global__ __launch_bounds__(1024) void k_merge_finalize(const Cand32* __restric
 
     // phase 2: exact f64 rescoring of the candidates
     Acc64<METRIC> A;
-    rescore_rows_par<METRIC>(master, q64, dim, sh_pos, n_cand, rs, A);
+    VL_STAMP(3);
+    rescore_rows_par<METRIC>(master, q64, dim, sh_pos, n_cand, rs, A, q_first);
+    VL_STAMP(8);
 
     // phase 3: rank by (score desc, pos asc), bound check, emit
     if (wave == 0) {
         const bool valid = lane < n_cand;
         const double sc = valid ? A.score() : 0.0;
         const uint32_t my_pos = sh_pos[lane];
-        sh_score[lane] = sc;
-        __builtin_amdgcn_wave_barrier();
         const bool any_nan = __ballot(valid && sc != sc) != 0ull;
+        // rank = how many candidates stand in front of this one: every candidate sits in a lane of this wave, so
+        // entry j is read with v_readlane (a scalar operand of the compares), no LDS round trip per entry
         int rank = 0;
+#pragma unroll 8
         for (int j = 0; j < n_cand; ++j) {
-            const double sj = sh_score[j];
-            const uint32_t pj = sh_pos[j];
+            const double sj = read_lane(sc, j);
+            const uint32_t pj = read_lane(my_pos, j);
             rank += (sj > sc || (sj == sc && pj < my_pos)) ? 1 : 0;
         }
         const uint32_t k_eff = (uint64_t)k < n_rows ? k : (uint32_t)n_rows;
@@ -648,12 +679,14 @@ __global__ __launch_bounds__(1024) void k_merge_finalize(const Cand32* __restric
             out->n_out = k_eff;
             out->flags = flags;
         }
+        VL_STAMP(9);
         if (seq) {
             // the host spins on out->seq (pinned memory): every lane's stores of the block above are complete at
             // system scope before the stamp leaves (wave 0 is the only writer of the block)
             __threadfence_system();
             if (lane == 0) __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        VL_STAMP(10);
     }
 }
 
@@ -686,6 +719,8 @@ __global__ __launch_bounds__(1024) void k_merge_finalize_multi(const Cand32* __r
     const double Q = q_norms[0];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
+    double q_first = 0.0;
+    if (threadIdx.x < RP_BW) q_first = q64[threadIdx.x < dim ? threadIdx.x : dim - 1];
     if (threadIdx.x == 0) {
         sh_flags = 0;
         sh_has_cut = 0;
@@ -710,7 +745,7 @@ __global__ __launch_bounds__(1024) void k_merge_finalize_multi(const Cand32* __r
     // phase 2: exact f64 rescoring, 64 rows at a time through the same LDS tile
     for (int p = 0; p < n_parts; ++p) {
         Acc64<METRIC> A;
-        rescore_rows_par<METRIC>(master, q64, dim, sh_pos + p * KP, sh_ncand[p], rs, A);
+        rescore_rows_par<METRIC>(master, q64, dim, sh_pos + p * KP, sh_ncand[p], rs, A, q_first);
         if (wave == 0) sh_score[p * KP + lane] = lane < sh_ncand[p] ? A.score() : 0.0;
         __syncthreads();
     }
@@ -1313,6 +1348,13 @@ int scan_grid(uint64_t n, const ScanShape& sh, const void* kernel)
     return (int)blocks;
 }
 }  // namespace
+
+#ifdef VL_DBG_STAMPS
+extern "C" int vl_dbg_read_stamps(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(vl_dbg_stamps), sizeof(unsigned long long) * 32);
+}
+#endif
 
 bool scan_takes_qarg(uint32_t ld)
 {

@@ -53,12 +53,14 @@ public:
     explicit ShardMerger(int device) : device_(device) {}
     ~ShardMerger();
     int ensure(uint64_t world, uint64_t nq, uint64_t ks, uint64_t k_out);
+    int ensure_stream();
+    bool needs_growth(uint64_t world, uint64_t nq, uint64_t ks, uint64_t k_out) const;  // would ensure() allocate?
     // gathered records already on the host (another transport did the exchange): H2D, merge, D2H
     int merge_host(const unsigned long long* gathered, uint32_t world, uint64_t nq, uint64_t ks, uint64_t k,
                    uint64_t* out_gpos, uint64_t* out_ids, double* out_scores, uint64_t* out_n);
     // after the collective filled d_recv(): merge + copy out (k = the caller's row stride)
     int merge_device(uint32_t world, uint64_t nq, uint64_t ks, uint64_t k, uint64_t* out_gpos, uint64_t* out_ids,
-                     double* out_scores, uint64_t* out_n);
+                     double* out_scores, uint64_t* out_n, hipEvent_t done = nullptr);  // `done`: recorded behind the D2H copy
     hipStream_t stream() const { return stream_; }
     unsigned long long* d_send() const { return d_send_; }
     unsigned long long* d_recv() const { return d_recv_; }
@@ -91,9 +93,23 @@ public:
     int search_batch(const GpuFlatIndex* shard, const double* queries, uint64_t nq, uint64_t q_len, uint64_t k, int metric,
                      uint64_t* out_gpos, uint64_t* out_ids, double* out_scores, uint64_t* out_n,
                      bool queries_on_device = false);
+    // where a batch's time goes, summed over calls: the local search (host clock), and on the exchange stream (HIP
+    // events) the H2D copy of this rank's record, the ncclAllGather, the merge kernel + D2H of the answer
+    void profile_enable(bool on);
+    void profile_read(uint64_t* calls, double* local_ms, double* h2d_ms, double* allgather_ms, double* merge_ms);
 
 private:
     ShardComm(int world, int rank, int device) : world_(world), rank_(rank), merger_(device) {}
+    int fail_and_abort(int rc);
+    int exchange_status(unsigned long long mine, unsigned long long* first_bad, int* bad_rank);
+    int ensure_exchange(uint64_t nq, uint64_t ks, uint64_t k_out);
+    bool dead_ = false;                         // aborted after a local failure in front of a collective
+    unsigned long long* d_status_ = nullptr;    // [8] send + [2 * world] receive, made at create()
+    unsigned long long* h_status_ = nullptr;    // pinned, same shape
+    hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool profile_ = false;
+    uint64_t prof_calls_ = 0;
+    double prof_local_ms_ = 0.0, prof_h2d_ms_ = 0.0, prof_allgather_ms_ = 0.0, prof_merge_ms_ = 0.0;
     int world_, rank_;
     void* comm_ = nullptr;  // ncclComm_t
     ShardMerger merger_;

@@ -3,6 +3,8 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -103,6 +105,19 @@ ShardMerger::~ShardMerger()
 
 static uint64_t out_words(uint64_t nq, uint64_t k_out) { return 3 * nq * k_out + nq + 2; }
 
+int ShardMerger::ensure_stream()
+{
+    SH_HIP(hipSetDevice(device_));
+    if (!stream_) SH_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    return OK;
+}
+
+bool ShardMerger::needs_growth(uint64_t world, uint64_t nq, uint64_t ks, uint64_t k_out) const
+{
+    const uint64_t words = shard_packed_words(nq, ks);
+    return !stream_ || words > send_cap_ || words * world > recv_cap_ || out_words(nq, k_out) > out_cap_;
+}
+
 int ShardMerger::ensure(uint64_t world, uint64_t nq, uint64_t ks, uint64_t k_out)
 {
     SH_HIP(hipSetDevice(device_));
@@ -140,7 +155,7 @@ int ShardMerger::ensure(uint64_t world, uint64_t nq, uint64_t ks, uint64_t k_out
 }
 
 int ShardMerger::merge_device(uint32_t world, uint64_t nq, uint64_t ks, uint64_t k, uint64_t* out_gpos,
-                              uint64_t* out_ids, double* out_scores, uint64_t* out_n)
+                              uint64_t* out_ids, double* out_scores, uint64_t* out_n, hipEvent_t done)
 {
     const uint64_t k_out = std::min<uint64_t>(k, (uint64_t)world * ks);
     const uint64_t plane = nq * k_out;
@@ -152,6 +167,7 @@ int ShardMerger::merge_device(uint32_t world, uint64_t nq, uint64_t ks, uint64_t
     SH_HIP(launch_shard_merge(stream_, d_recv_, world, (uint32_t)nq, (uint32_t)ks, (uint32_t)k_out, d_gpos, d_ids, d_scores,
                               d_n, d_st));
     SH_HIP(hipMemcpyAsync(h_out_, d_out_, out_words(nq, k_out) * 8, hipMemcpyDeviceToHost, stream_));
+    if (done) SH_HIP(hipEventRecord(done, stream_));
     SH_HIP(hipStreamSynchronize(stream_));
     const unsigned long long st = h_out_[3 * plane + nq], rk = h_out_[3 * plane + nq + 1];
     if (st != 0) {
@@ -221,33 +237,137 @@ int ShardComm::create(const uint8_t id_bytes[SHARD_ID_BYTES], int world, int ran
         return ERR_DEVICE;
     }
     c->comm_ = comm;
+    // what every later collective may need without allocating: the exchange stream, the 8 + 2 * world word status
+    // buffers (sync's table, the pre-flight of a growing exchange) and the timing events
+    const size_t sw = 8 + 2 * (size_t)world;
+    if (c->merger_.ensure_stream() != OK || hipMalloc(reinterpret_cast<void**>(&c->d_status_), sw * 8) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&c->h_status_), sw * 8, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        set_last_error("vl_comm_create: could not allocate the status exchange buffers");
+        delete c;  // collective resources are released; the peers' next collective on this communicator fails
+        return ERR_OOM;
+    }
+    for (auto& e : c->ev_)
+        if (hipEventCreate(&e) != hipSuccess) {
+            (void)hipGetLastError();
+            delete c;
+            return ERR_DEVICE;
+        }
     *out = c;
     return OK;
 }
 
 ShardComm::~ShardComm()
 {
+    (void)hipSetDevice(merger_.device());
+    if (comm_) (void)ncclCommDestroy(static_cast<ncclComm_t>(comm_));
+    if (d_status_) (void)hipFree(d_status_);
+    if (h_status_) (void)hipHostFree(h_status_);
+    for (auto& e : ev_)
+        if (e) (void)hipEventDestroy(e);
+}
+
+// A rank that cannot reach a collective its peers are about to post must not simply return: they would wait in
+// the all-gather for ever.  Whatever fails locally BEFORE a collective is therefore either carried into it (word 0
+// of the record; the pre-flight status exchange below for buffer growth) or, for a device failure that leaves no
+// way to take part (hipSetDevice / a copy on the exchange stream), ends with ncclCommAbort: the peers' collective
+// then fails instead of hanging, and this communicator refuses every later call.
+int ShardComm::fail_and_abort(int rc)
+{
     if (comm_) {
-        (void)hipSetDevice(merger_.device());
-        (void)ncclCommDestroy(static_cast<ncclComm_t>(comm_));
+        (void)ncclCommAbort(static_cast<ncclComm_t>(comm_));
+        comm_ = nullptr;
     }
+    dead_ = true;
+    synced_ = false;
+    set_last_error(std::string(last_error()) + " (before a collective: communicator aborted so that the other ranks fail instead of waiting)");
+    return rc;
+}
+
+#define SH_HIP_OR_ABORT(expr)                                                          \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_));        \
+            return fail_and_abort((e_ == hipErrorOutOfMemory) ? (int)ERR_OOM : (int)ERR_DEVICE); \
+        }                                                                             \
+    } while (0)
+
+// collective: every rank's `mine` (0 = fine) -> the first non-zero status of any rank, through the 8-word buffers
+// made at create(): nothing is allocated on the way
+int ShardComm::exchange_status(unsigned long long mine, unsigned long long* first_bad, int* bad_rank)
+{
+    h_status_[0] = mine;
+    SH_HIP_OR_ABORT(hipSetDevice(merger_.device()));
+    SH_HIP_OR_ABORT(hipMemcpyAsync(d_status_, h_status_, 8, hipMemcpyHostToDevice, merger_.stream()));
+    const ncclResult_t r = ncclAllGather(d_status_, d_status_ + 8, 1, ncclUint64, static_cast<ncclComm_t>(comm_), merger_.stream());
+    if (r != ncclSuccess) {
+        set_last_error(std::string("ncclAllGather (status): ") + ncclGetErrorString(r));
+        return fail_and_abort(ERR_DEVICE);
+    }
+    SH_HIP_OR_ABORT(hipMemcpyAsync(h_status_ + 8, d_status_ + 8, (size_t)world_ * 8, hipMemcpyDeviceToHost, merger_.stream()));
+    SH_HIP(hipStreamSynchronize(merger_.stream()));
+    *first_bad = 0;
+    *bad_rank = -1;
+    for (int r2 = 0; r2 < world_; ++r2)
+        if (h_status_[8 + r2] != 0) {
+            *first_bad = h_status_[8 + r2];
+            *bad_rank = r2;
+            break;
+        }
+    return OK;
+}
+
+// Buffers for an exchange of (nq, ks): whether they have to grow depends only on the history of (nq, ks, world) --
+// the same on every rank -- so all ranks take the pre-flight together or skip it together; a rank whose allocation
+// fails says so THERE and every rank returns VL_ERR_OOM, nobody is left in the big all-gather.
+int ShardComm::ensure_exchange(uint64_t nq, uint64_t ks, uint64_t k_out)
+{
+    if (!merger_.needs_growth((uint64_t)world_, nq, ks, k_out)) return OK;
+    int rc = merger_.ensure((uint64_t)world_, nq, ks, k_out);
+    if (const char* inj = getenv("VL_SHARD_INJECT_OOM"))  // tests: "<rank>" makes that rank's growth fail
+        if (atoi(inj) == rank_) {
+            set_last_error("injected allocation failure (VL_SHARD_INJECT_OOM)");
+            rc = ERR_OOM;
+        }
+    const std::string local_msg = rc != OK ? std::string(last_error()) : std::string();
+    unsigned long long bad = 0;
+    int bad_rank = -1;
+    const int xrc = exchange_status((unsigned long long)rc, &bad, &bad_rank);
+    if (xrc != OK) return xrc;
+    if (bad != 0) {
+        set_last_error("shard rank " + std::to_string(bad_rank) + " could not size its exchange buffers (status " +
+                       std::to_string(bad) + ")" + (local_msg.empty() ? "" : "; this rank: " + local_msg));
+        return (int)bad;
+    }
+    return OK;
 }
 
 int ShardComm::sync(const GpuFlatIndex* shard, uint64_t* out_offset, uint64_t* out_total)
 {
     if (!shard) return ERR_INVALID_ARG;
     std::lock_guard<std::mutex> g(mu_);
+    if (dead_) {
+        set_last_error("this communicator was aborted after a local failure");
+        return ERR_DEVICE;
+    }
     synced_ = false;
-    int rc = merger_.ensure((uint64_t)world_, 1, 1, 1);  // >= 8 words each way
-    if (rc != OK) return rc;
-    unsigned long long* h = merger_.h_send();
-    h[0] = shard->len();
-    h[1] = shard->dimension();
-    SH_HIP(hipMemcpyAsync(merger_.d_send(), h, 2 * 8, hipMemcpyHostToDevice, merger_.stream()));
-    SH_NCCL(ncclAllGather(merger_.d_send(), merger_.d_recv(), 2, ncclUint64, static_cast<ncclComm_t>(comm_), merger_.stream()));
+    // (len, dim) travel through the status buffers of create(): no allocation between here and the collective
+    h_status_[0] = shard->len();
+    h_status_[1] = shard->dimension();
+    SH_HIP_OR_ABORT(hipSetDevice(merger_.device()));
+    SH_HIP_OR_ABORT(hipMemcpyAsync(d_status_, h_status_, 2 * 8, hipMemcpyHostToDevice, merger_.stream()));
+    {
+        const ncclResult_t r = ncclAllGather(d_status_, d_status_ + 8, 2, ncclUint64, static_cast<ncclComm_t>(comm_), merger_.stream());
+        if (r != ncclSuccess) {
+            set_last_error(std::string("ncclAllGather (sync): ") + ncclGetErrorString(r));
+            return fail_and_abort(ERR_DEVICE);
+        }
+    }
     std::vector<unsigned long long> all(2 * (size_t)world_);
-    SH_HIP(hipMemcpyAsync(all.data(), merger_.d_recv(), all.size() * 8, hipMemcpyDeviceToHost, merger_.stream()));
+    SH_HIP_OR_ABORT(hipMemcpyAsync(h_status_ + 8, d_status_ + 8, all.size() * 8, hipMemcpyDeviceToHost, merger_.stream()));
     SH_HIP(hipStreamSynchronize(merger_.stream()));
+    std::memcpy(all.data(), h_status_ + 8, all.size() * 8);
     lens_.assign((size_t)world_, 0);
     uint64_t off = 0, total = 0, mx = 0;
     for (int r = 0; r < world_; ++r) {
@@ -285,6 +405,10 @@ int ShardComm::search_batch(const GpuFlatIndex* shard, const double* queries, ui
         return ERR_INVALID_ARG;
     }
     std::lock_guard<std::mutex> g(mu_);
+    if (dead_) {
+        set_last_error("this communicator was aborted after a local failure");
+        return ERR_DEVICE;
+    }
     // Everything decided before the collective is a function of the arguments (the same on every rank by
     // contract) and of the table agreed at the last sync(): all ranks return early together or go on together.
     if (!synced_) {
@@ -300,20 +424,64 @@ int ShardComm::search_batch(const GpuFlatIndex* shard, const double* queries, ui
         set_last_error("vl_shard_search_batch: nq x k too large for one exchange");
         return ERR_INVALID_ARG;
     }
-    int rc = merger_.ensure((uint64_t)world_, nq, ks, k_out);
+    int rc = ensure_exchange(nq, ks, k_out);  // collective when the buffers have to grow (the same on every rank)
     if (rc != OK) return rc;
+    const bool prof = profile_;
+    const auto t_local = std::chrono::steady_clock::now();
+    // from here to the all-gather nothing returns: a local failure travels in word 0 of this rank's record
     shard_search_local(shard, offset_, lens_[(size_t)rank_], total_ != 0, queries, nq, q_len, ks, metric, merger_.h_send(),
                        queries_on_device);
+    const double local_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_local).count();
     const std::string local_msg = merger_.h_send()[0] != 0 ? std::string(last_error()) : std::string();
-    SH_HIP(hipSetDevice(merger_.device()));
-    SH_HIP(hipMemcpyAsync(merger_.d_send(), merger_.h_send(), words * 8, hipMemcpyHostToDevice, merger_.stream()));
+    SH_HIP_OR_ABORT(hipSetDevice(merger_.device()));
+    if (prof) SH_HIP_OR_ABORT(hipEventRecord(ev_[0], merger_.stream()));
+    SH_HIP_OR_ABORT(hipMemcpyAsync(merger_.d_send(), merger_.h_send(), words * 8, hipMemcpyHostToDevice, merger_.stream()));
+    if (prof) SH_HIP_OR_ABORT(hipEventRecord(ev_[1], merger_.stream()));
     // THE exchange step of the path: one all-gather of per-shard top-k records (config 3: 1024 queries x k 10
     // -> 254 KB per rank), latency-bound on xGMI -- one collective, not a ring of small ones
-    SH_NCCL(ncclAllGather(merger_.d_send(), merger_.d_recv(), words, ncclUint64, static_cast<ncclComm_t>(comm_),
-                          merger_.stream()));
-    rc = merger_.merge_device((uint32_t)world_, nq, ks, k, out_gpos, out_ids, out_scores, out_n);
+    {
+        const ncclResult_t r = ncclAllGather(merger_.d_send(), merger_.d_recv(), words, ncclUint64,
+                                             static_cast<ncclComm_t>(comm_), merger_.stream());
+        if (r != ncclSuccess) {
+            set_last_error(std::string("ncclAllGather: ") + ncclGetErrorString(r));
+            return fail_and_abort(ERR_DEVICE);
+        }
+    }
+    if (prof) SH_HIP(hipEventRecord(ev_[2], merger_.stream()));
+    rc = merger_.merge_device((uint32_t)world_, nq, ks, k, out_gpos, out_ids, out_scores, out_n, prof ? ev_[3] : nullptr);
+    if (prof) {  // merge_device has synchronised the stream (or failed before its event: the read below then fails too)
+        float h2d = 0.f, ag = 0.f, mg = 0.f;
+        if (hipEventElapsedTime(&h2d, ev_[0], ev_[1]) == hipSuccess && hipEventElapsedTime(&ag, ev_[1], ev_[2]) == hipSuccess &&
+            hipEventElapsedTime(&mg, ev_[2], ev_[3]) == hipSuccess) {
+            prof_calls_ += 1;
+            prof_local_ms_ += local_ms;
+            prof_h2d_ms_ += h2d;
+            prof_allgather_ms_ += ag;
+            prof_merge_ms_ += mg;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     if (rc != OK && !local_msg.empty()) set_last_error(std::string(last_error()) + "; this rank: " + local_msg);
     return rc;
+}
+
+void ShardComm::profile_enable(bool on)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    profile_ = on;
+}
+
+void ShardComm::profile_read(uint64_t* calls, double* local_ms, double* h2d_ms, double* allgather_ms, double* merge_ms)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    if (calls) *calls = prof_calls_;
+    if (local_ms) *local_ms = prof_local_ms_;
+    if (h2d_ms) *h2d_ms = prof_h2d_ms_;
+    if (allgather_ms) *allgather_ms = prof_allgather_ms_;
+    if (merge_ms) *merge_ms = prof_merge_ms_;
+    prof_calls_ = 0;
+    prof_local_ms_ = prof_h2d_ms_ = prof_allgather_ms_ = prof_merge_ms_ = 0.0;
 }
 
 }  // namespace vl

@@ -109,6 +109,16 @@ class Comm:
     def rank(self) -> int:
         return int(self._L.vl_comm_rank(self._h))
 
+    def profile_enable(self, on: bool = True) -> None:
+        self._L.vl_comm_profile_enable(self._h, 1 if on else 0)
+
+    def profile_read(self) -> dict:
+        """Totals since the last read: calls, local search ms (host clock), and on the exchange stream (HIP events)
+        the record's H2D copy, the ncclAllGather, the merge kernel + D2H."""
+        calls, a, b, c, d = C.c_uint64(0), C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0)
+        self._L.vl_comm_profile_read(self._h, C.byref(calls), C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return {"calls": int(calls.value), "local_ms": a.value, "h2d_ms": b.value, "allgather_ms": c.value, "merge_ms": d.value}
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.vl_comm_destroy(self._h)
