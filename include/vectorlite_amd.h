@@ -77,6 +77,30 @@ int vl_flat_create(uint64_t dim, int device, vl_index **out);
 int vl_flat_from_rows(uint64_t dim, const uint64_t *ids, const double *values, uint64_t n, int device,
                       vl_index **out);
 
+/* ONE flat index over several GPUs of the node, in ONE process (the reference is one process: collections live in
+ * Arc<RwLock<..>>, src/client.rs:243-247; searches run under read() on any tokio worker, src/client.rs:398,
+ * src/server.rs:269,379-392).  The handle answers every vl_index_* entry point like a vl_flat_create handle
+ * (VectorIndexWrapper::Flat); no per-GPU process, no id handshake.  device_ids[n_dev]: HIP ordinals, one part each
+ * (an ordinal listed twice makes two parts on that card).
+ *   VL_MULTI_REPLICAS    every GPU holds every row; add / delete go to all of them; a vl_index_search is answered by
+ *                        the replica with the fewest searches in flight, on the calling thread (concurrent callers
+ *                        spread over the GPUs; vl_index_set_coalescing gives each replica its own queue); a
+ *                        vl_index_search_batch is cut into one run of queries per replica.
+ *   VL_MULTI_ROW_SHARDS  every GPU holds part of the rows (add appends to the shortest shard; bulk adds are cut into
+ *                        contiguous runs that level the shards).  Every search runs on all shards side by side, the
+ *                        per-shard exact top-k are merged on the first GPU by (score desc, insertion order asc): the
+ *                        answer is bit-identical to one index holding every row (src/index/flat.rs:116).
+ * Device-side inputs (values_on_device, embeddings_on_device, d_queries) are expected on device_ids[0].
+ * vl_index_search_positions returns global insertion numbers for a row-sharded handle. */
+#define VL_MULTI_REPLICAS 0
+#define VL_MULTI_ROW_SHARDS 1
+int vl_flat_create_multi(uint64_t dim, const int *device_ids, int n_dev, int mode, vl_index **out);
+
+/* Parts of a handle (1 for a single-GPU handle, mode -1): rows held by each part and searches each has answered
+ * (queries, for batches) -- how evenly the replica dealer / the shard filler spread the work.  rows / searches hold
+ * `capacity` entries and are filled when capacity >= *n_parts; any pointer may be NULL. */
+int vl_index_parts(const vl_index *h, int *n_parts, int *mode, uint64_t *rows, uint64_t *searches, int capacity);
+
 /* HNSWIndex::new(dim, metric) (src/index/hnsw.rs:216-259), default cargo profile M = 16, M0 = 32
  * (src/index/hnsw.rs:95-109).  The handle then behaves like VectorIndexWrapper::HNSW
  * (src/lib.rs:271-327) under every vl_index_* trait entry point below: add validates dimension and

@@ -40,7 +40,8 @@ int main(void)
     const double q[3] = {1, 0, 0};
     uint64_t ids[2], n = 0;
     double scores[2];
-    CHECK(vl_index_search(idx, q, 3, 2, VL_COSINE, ids, scores, &n));
+    /* k = 10 asked, two slots offered: min(k, len, capacity) results are written (vl_index_search_cap) */
+    CHECK(vl_index_search_cap(idx, q, 3, 10, VL_COSINE, 2, ids, scores, &n));
     printf("flat: n=%llu first id=%llu score=%.17g\n", (unsigned long long)n, (unsigned long long)ids[0], scores[0]);
     if (n != 2 || ids[0] != 1 || fabs(scores[0] - 1.0) > 1e-10) return 1;
 
@@ -52,12 +53,32 @@ int main(void)
     const double qs[2][3] = {{0, 1, 0}, {0.1, 0.1, 1.1}};
     uint64_t bids[2 * 2], bn[2];
     double bscores[2 * 2];
-    CHECK(vl_index_search_batch(idx, &qs[0][0], 2, 3, 2, VL_EUCLIDEAN, bids, bscores, bn));
+    CHECK(vl_index_search_batch_cap(idx, &qs[0][0], 2, 3, 5, VL_EUCLIDEAN, 2, bids, bscores, bn)); /* rows 2 apart */
     printf("batch: first ids %llu %llu\n", (unsigned long long)bids[0], (unsigned long long)bids[2]);
     if (bids[0] != 2 || bids[2] != 3) return 1;
     CHECK(vl_index_delete(idx, 2));
     CHECK(vl_index_delete(idx, 2)); /* absent id: still Ok for the flat index (src/index/flat.rs:93-96) */
     if (vl_index_len(idx) != 2) return 1;
+
+    /* the same index over two GPUs of the node in this one process (here: the same card twice), rows sharded:
+     * identical answers, no rank processes, no id handshake */
+    {
+        vl_index *multi = NULL;
+        const int devs[2] = {0, 0};
+        CHECK(vl_flat_create_multi(3, devs, 2, VL_MULTI_ROW_SHARDS, &multi));
+        for (uint64_t i = 0; i < 3; ++i) CHECK(vl_index_add(multi, i + 1, rows[i], 3));
+        if (vl_index_add(multi, 3, rows[0], 3) != VL_ERR_DUP_ID) return 1; /* wherever id 3 lives */
+        uint64_t mids[3], mn = 0;
+        double msc[3];
+        CHECK(vl_index_search_cap(multi, q, 3, 3, VL_COSINE, 3, mids, msc, &mn));
+        int parts = 0, mode = -1;
+        uint64_t prow[2] = {0, 0};
+        CHECK(vl_index_parts(multi, &parts, &mode, prow, NULL, 2));
+        printf("multi: %d parts (mode %d) holding %llu + %llu rows; best id %llu\n", parts, mode, (unsigned long long)prow[0],
+               (unsigned long long)prow[1], (unsigned long long)mids[0]);
+        if (mn != 3 || mids[0] != 1 || mids[1] != 2 || mids[2] != 3 || parts != 2 || prow[0] + prow[1] != 3) return 1;
+        vl_index_destroy(multi);
+    }
     vl_index_destroy(idx);
 
     /* the ingest step in front of add: f32 model output, widened and L2-normalised on the device exactly as

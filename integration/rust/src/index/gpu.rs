@@ -40,6 +40,9 @@ extern "C" {
     fn vl_index_add_embeddings_f32(h: *mut vl_index, ids: *const u64, embeddings: *const f32, n: u64, normalize: c_int, validate: c_int, embeddings_on_device: c_int) -> c_int;
     fn vl_index_delete(h: *mut vl_index, id: u64) -> c_int;
     fn vl_index_search(h: *const vl_index, query: *const f64, q_len: u64, k: u64, metric: c_int, out_ids: *mut u64, out_scores: *mut f64, out_n: *mut u64) -> c_int;
+    fn vl_index_search_cap(h: *const vl_index, query: *const f64, q_len: u64, k: u64, metric: c_int, out_capacity: u64, out_ids: *mut u64, out_scores: *mut f64, out_n: *mut u64) -> c_int;
+    fn vl_index_search_batch_cap(h: *const vl_index, queries: *const f64, nq: u64, q_len: u64, k: u64, metric: c_int, out_stride: u64, out_ids: *mut u64, out_scores: *mut f64, out_n: *mut u64) -> c_int;
+    fn vl_flat_create_multi(dim: u64, device_ids: *const c_int, n_dev: c_int, mode: c_int, out: *mut *mut vl_index) -> c_int;
     fn vl_index_len(h: *const vl_index) -> u64;
     fn vl_index_get_vector(h: *const vl_index, id: u64, out: *mut f64) -> c_int;
     fn vl_index_export(h: *const vl_index, out_ids: *mut u64, out_values: *mut f64) -> c_int;
@@ -128,14 +131,13 @@ impl Handle {
     }
 
     fn search(&self, query: &[f64], k: usize, metric: SimilarityMetric) -> VectorLiteResult<Vec<SearchResult>> {
-        // The library writes min(k, len at search time) entries and takes no capacity argument, so the k handed
-        // over is clamped to the buffer: results for a smaller k are a prefix of those for a larger one, and the
-        // call can never write past `cap` even if another handle user grew the index after len() was read
-        // (in Rust `&mut self` on add already excludes that; a C or Python caller has no such lock).
+        // vl_index_search_cap writes min(k, len at search time, cap) entries: the bound is this buffer's own size,
+        // whatever the index length is by the time the search runs (in Rust `&mut self` on add already excludes a
+        // concurrent grow; a C or Python caller has no such lock).
         let cap = k.min(self.len()).max(1);
         let (mut ids, mut scores, mut n) = (vec![0u64; cap], vec![0f64; cap], 0u64);
         let rc = unsafe {
-            vl_index_search(self.raw, query.as_ptr(), query.len() as u64, k.min(cap) as u64, metric_code(metric), ids.as_mut_ptr(), scores.as_mut_ptr(), &mut n)
+            vl_index_search_cap(self.raw, query.as_ptr(), query.len() as u64, k as u64, metric_code(metric), cap as u64, ids.as_mut_ptr(), scores.as_mut_ptr(), &mut n)
         };
         match rc {
             VL_OK => Ok((0..n as usize)
@@ -207,6 +209,44 @@ impl GpuFlatIndex {
     }
 }
 
+/// How `GpuFlatIndex::new_multi` spreads one index over the GPUs of the node (include/vectorlite_amd.h).
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
+pub enum MultiGpuMode {
+    /// every GPU holds every row; concurrent `search` calls (tokio workers under `RwLock::read`, src/client.rs:398)
+    /// are dealt to the least busy replica
+    Replicas = 0,
+    /// every GPU holds part of the rows; each search runs on all of them, exact per-shard top-k merged on the device
+    RowShards = 1,
+}
+
+impl GpuFlatIndex {
+    /// `FlatIndex::new(dim, data)` over several GPUs in THIS process (`vl_flat_create_multi`): the value behaves as any
+    /// other `GpuFlatIndex` behind `VectorIndexWrapper` -- same trait, same results -- but the server's one
+    /// `Arc<RwLock<Collection>>` (src/client.rs:243-247) now keeps all `devices` busy.  No rank processes, no id handshake.
+    pub fn new_multi(dim: usize, data: Vec<Vector>, devices: &[i32], mode: MultiGpuMode) -> Self {
+        let mut raw = std::ptr::null_mut();
+        let devs: Vec<c_int> = devices.iter().map(|d| *d as c_int).collect();
+        let rc = unsafe { vl_flat_create_multi(dim as u64, devs.as_ptr(), devs.len() as c_int, mode as c_int, &mut raw) };
+        assert_eq!(rc, VL_OK, "vl_flat_create_multi: {}", last_error());
+        let ids: Vec<u64> = data.iter().map(|v| v.id).collect();
+        let mut values = Vec::with_capacity(data.len() * dim);
+        for v in &data {
+            values.extend_from_slice(&v.values);
+        }
+        if !ids.is_empty() {
+            // FlatIndex::new validates nothing (src/index/flat.rs:68-73): validate = 0
+            let rc = unsafe { vl_index_add_bulk(raw, ids.as_ptr(), values.as_ptr(), ids.len() as u64, 0, 0) };
+            assert_eq!(rc, VL_OK, "vl_index_add_bulk: {}", last_error());
+        }
+        let mut side = Side::new();
+        for v in data {
+            side.entry(v.id).or_insert((v.text, v.metadata));
+        }
+        unsafe { vl_index_set_coalescing(raw, 64, 200) }; // one queue per replica
+        GpuFlatIndex(Handle { raw, dim, side })
+    }
+}
+
 impl GpuFlatIndex {
     /// The ingest step of `Collection::add_text` for a batch (`src/client.rs:313-345`): the embedding model's raw
     /// f32 outputs are widened and L2-normalised on the device exactly as `EmbeddingGenerator::generate_embedding`
@@ -226,14 +266,15 @@ impl GpuFlatIndex {
     pub fn search_batch(&self, queries: &[f64], nq: usize, k: usize, metric: SimilarityMetric) -> VectorLiteResult<Vec<Vec<(u64, f64)>>> {
         let dim = self.0.dim;
         assert_eq!(queries.len(), nq * dim);
-        let (mut ids, mut scores, mut n) = (vec![0u64; nq * k.max(1)], vec![0f64; nq * k.max(1)], vec![0u64; nq]);
+        let stride = k.min(self.len()).max(1); // rows of the output: the library writes min(k, len, stride) entries each
+        let (mut ids, mut scores, mut n) = (vec![0u64; nq * stride], vec![0f64; nq * stride], vec![0u64; nq]);
         let rc = unsafe {
-            vl_index_search_batch(self.0.raw, queries.as_ptr(), nq as u64, dim as u64, k as u64, metric_code(metric), ids.as_mut_ptr(), scores.as_mut_ptr(), n.as_mut_ptr())
+            vl_index_search_batch_cap(self.0.raw, queries.as_ptr(), nq as u64, dim as u64, k as u64, metric_code(metric), stride as u64, ids.as_mut_ptr(), scores.as_mut_ptr(), n.as_mut_ptr())
         };
         if rc != VL_OK {
             return Err(VectorLiteError::InternalError(last_error()));
         }
-        Ok((0..nq).map(|q| (0..n[q] as usize).map(|i| (ids[q * k + i], scores[q * k + i])).collect()).collect())
+        Ok((0..nq).map(|q| (0..n[q] as usize).map(|i| (ids[q * stride + i], scores[q * stride + i])).collect()).collect())
     }
 
     /// The embed -> search step of `Collection::search_text` (src/client.rs:393-401) for a batch: `embeddings` is `[nq, dim]`

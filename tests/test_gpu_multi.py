@@ -1,0 +1,188 @@
+"""ONE flat-index handle over several GPUs in one process (vl_flat_create_multi; the reference is one process with
+its collections behind Arc<RwLock<..>>, src/client.rs:243-247,398).  The test box has one card, so the parts are
+made on the same device -- device_ids = {0}, {0, 0}, {0, 0, 0} -- which runs the same host code (per-part worker
+threads, replica dealing, per-shard search + device merge) that eight cards would.  Every answer is compared with
+ONE oracle holding all rows in insertion order: ids and f64 scores ==."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _unit(rng, n, dim):
+    x = rng.standard_normal((n, dim))
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+def _same(got, want):
+    gi, gs = got
+    wi, ws = want
+    assert gi.tolist() == wi.tolist()
+    assert gs.tolist() == ws.tolist()
+
+
+@pytest.mark.parametrize("mode", ["replicas", "row_shards"])
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_trait_surface_matches_one_oracle(mode, devices):
+    import vectorlite_amd as V
+    from oracle import oracle as O
+    rng = np.random.default_rng(7 + len(devices))
+    dim, n = 48, 3000
+    rows = _unit(rng, n, dim)
+    rows[100] = rows[5]          # equal rows: ties broken by insertion order, across shards too
+    rows[2000] = rows[5]
+    rows[2999] = rows[5]
+    ids = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(17)) % np.uint64(2 ** 48)
+    m = V.MultiFlatIndex(dim, devices, mode)
+    ref = O.FlatOracle(dim)
+    # bulk load in uneven pieces (the shards level out), then single adds
+    for a, b in ((0, 1000), (1000, 1001), (1001, 2500)):
+        m.add_rows(ids[a:b], rows[a:b], validate=False)
+        ref.extend(ids[a:b], rows[a:b])
+    for i in range(2500, n):
+        m.add(V.Vector(int(ids[i]), rows[i]))
+        ref.add(int(ids[i]), rows[i])
+    assert len(m) == n == len(ref)
+    parts = m.parts()
+    assert parts["n_parts"] == len(devices)
+    if mode == "row_shards":
+        assert sum(parts["rows"]) == n and max(parts["rows"]) - min(parts["rows"]) <= 1
+    else:
+        assert parts["rows"] == [n] * len(devices)
+    Q = _unit(rng, 24, dim)
+    Q[3] = rows[5]               # the query that hits the four equal rows
+    for metric in range(4):
+        for k in (1, 10, 60):
+            for qi in (0, 3, 7):
+                _same(m.search_arrays(Q[qi], k, metric), ref.search(Q[qi], k, metric))
+        bi, bs, bn = m.search_batch(Q, 10, metric)
+        for qi in range(len(Q)):
+            wi, ws = ref.search(Q[qi], 10, metric)
+            assert bn[qi] == len(wi) and bi[qi, :bn[qi]].tolist() == wi.tolist() and bs[qi, :bn[qi]].tolist() == ws.tolist()
+    # k larger than any one shard, and larger than the index
+    for k in (n // len(devices) + 5, n + 10):
+        _same(m.search_arrays(Q[1], k, 0), ref.search(Q[1], k, 0))
+    # duplicate id is refused wherever the first copy lives; dimension mismatch; delete of present and absent ids
+    with pytest.raises(V.IndexOpError, match=f"Vector ID {int(ids[2000])} already exists"):
+        m.add(V.Vector(int(ids[2000]), rows[1]))
+    with pytest.raises(V.IndexOpError, match="Vector dimension mismatch"):
+        m.add(V.Vector(123456789, rows[1][:5]))
+    with pytest.raises(V.DimensionMismatch) as e:
+        m.search_arrays(Q[0][:7], 3, 0)
+    assert (e.value.expected, e.value.actual) == (dim, 7)
+    for victim in (int(ids[5]), int(ids[1700]), int(ids[2999]), 999999999999):
+        m.delete(victim)
+        ref.delete(victim)
+    assert len(m) == len(ref) == n - 3
+    for metric in (0, 1):
+        _same(m.search_arrays(Q[3], 10, metric), ref.search(Q[3], 10, metric))
+    # point lookups and export follow insertion order of the WHOLE index
+    assert m.max_id() == int(max(int(i) for i in ids if int(i) not in (int(ids[5]), int(ids[1700]), int(ids[2999]))))
+    got = m.get_vector(int(ids[100]))
+    assert got is not None and np.array_equal(np.asarray(got.values), rows[100])
+    assert m.get_vector(int(ids[5])) is None
+    e_ids, e_vals = m.export()
+    keep = [i for i in range(n) if i not in (5, 1700, 2999)]
+    assert e_ids.tolist() == ids[keep].tolist() and np.array_equal(e_vals, rows[keep])
+    # a validated bulk add stops at the first duplicate, rows before it are kept (n sequential adds)
+    new_ids = np.array([7000001, 7000002, int(ids[10]), 7000003], dtype=np.uint64)
+    new_rows = _unit(rng, 4, dim)
+    with pytest.raises(V.IndexOpError, match=f"Vector ID {int(ids[10])} already exists"):
+        m.add_rows(new_ids, new_rows, validate=True)
+    ref.add(7000001, new_rows[0])
+    ref.add(7000002, new_rows[1])
+    assert len(m) == len(ref)
+    _same(m.search_arrays(new_rows[1], 5, 0), ref.search(new_rows[1], 5, 0))
+    # Clone answers like the original and is independent of it
+    c = m.clone()
+    m.delete(7000002)
+    _same(c.search_arrays(new_rows[1], 5, 0), ref.search(new_rows[1], 5, 0))
+    ref.delete(7000002)
+    _same(m.search_arrays(new_rows[1], 5, 0), ref.search(new_rows[1], 5, 0))
+
+
+def test_empty_and_tiny_sharded_indexes():
+    import vectorlite_amd as V
+    from oracle import oracle as O
+    m = V.MultiFlatIndex(4, [0, 0, 0], "row_shards")
+    assert len(m) == 0 and m.max_id() is None
+    i, s = m.search_arrays(np.ones(9), 3, 0)   # an empty index accepts any query length (src/index/flat.rs:99)
+    assert len(i) == 0
+    ref = O.FlatOracle(4)
+    rows = np.array([[1.0, 0, 0, 0], [0, 1.0, 0, 0]])
+    for j in range(2):                         # fewer rows than shards: one shard stays empty
+        m.add(V.Vector(10 + j, rows[j]))
+        ref.add(10 + j, rows[j])
+    for metric in range(4):
+        _same(m.search_arrays(np.array([0.6, 0.8, 0, 0]), 5, metric), ref.search(np.array([0.6, 0.8, 0, 0]), 5, metric))
+    with pytest.raises(V.DimensionMismatch):
+        m.search_arrays(np.ones(3), 1, 0)
+    # a NaN score with two or more rows in the index is the reference's panic, whichever shard holds the row
+    # (each shard here holds ONE row, whose own 1-element sort would never compare)
+    with pytest.raises(V.NaNScore):
+        m.search_arrays(np.array([np.nan, 0, 0, 0]), 1, 3)
+    one = V.MultiFlatIndex(4, [0, 0], "row_shards")
+    one.add(V.Vector(1, rows[0]))
+    i, s = one.search_arrays(np.array([np.nan, 0, 0, 0]), 1, 3)   # a 1-row index returns the NaN (no comparison happens)
+    assert i.tolist() == [1] and np.isnan(s[0])
+
+
+def test_concurrent_searches_are_dealt_over_the_replicas():
+    import vectorlite_amd as V
+    from oracle import oracle as O
+    rng = np.random.default_rng(99)
+    dim, n = 64, 40000
+    rows = _unit(rng, n, dim)
+    ids = np.arange(n, dtype=np.uint64) + np.uint64(5)
+    m = V.MultiFlatIndex(dim, [0, 0, 0], "replicas")
+    m.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    Q = _unit(rng, 48, dim)
+    want = [ref.search(q, 10, 0) for q in Q]
+    errors = []
+
+    def worker(t):
+        try:
+            for r in range(3):
+                for qi in range(t, len(Q), 6):
+                    _same(m.search_arrays(Q[qi], 10, 0), want[qi])
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert errors == []
+    p = m.parts()
+    assert sum(p["searches"]) == 3 * len(Q) and min(p["searches"]) > 0   # every replica took part
+    # a batch is cut into one run per replica; the rows come back in the caller's order
+    bi, bs, bn = m.search_batch(Q, 10, 0)
+    for qi in range(len(Q)):
+        assert bi[qi].tolist() == want[qi][0].tolist() and bs[qi].tolist() == want[qi][1].tolist()
+
+
+def test_sharded_batch_on_the_mfma_path_matches_one_index():
+    """Shards large enough for the bf16 MFMA filter (>= 8192 rows each), config 3's kind of batch: the merged answer is
+    the single index's, bit for bit, and device-side queries / f32 embeddings go through the same handle."""
+    import torch
+    import vectorlite_amd as V
+    rng = np.random.default_rng(3)
+    dim, n, nq = 128, 60000, 200
+    rows = _unit(rng, n, dim)
+    ids = np.arange(n, dtype=np.uint64) * np.uint64(3) + np.uint64(1)
+    one = V.FlatIndex(dim)
+    one.add_rows(ids, rows, validate=False)
+    m = V.MultiFlatIndex(dim, [0, 0, 0], "row_shards")
+    m.add_rows(ids, rows, validate=False)
+    Q = _unit(rng, nq, dim)
+    for metric in (0, 1, 3):
+        wi, ws, wn = one.search_batch(Q, 10, metric)
+        gi, gs, gn = m.search_batch(Q, 10, metric)
+        assert gn.tolist() == wn.tolist() and gi.tolist() == wi.tolist() and gs.tolist() == ws.tolist()
+    dQ = torch.from_numpy(Q).to("cuda:0")
+    di, ds, dn = m.search_batch_device(dQ, 10, 0)
+    wi, ws, wn = one.search_batch(Q, 10, 0)
+    assert di.tolist() == wi.tolist() and ds.tolist() == ws.tolist()

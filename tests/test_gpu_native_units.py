@@ -34,3 +34,18 @@ def test_plain_c_caller_runs_the_reference_kats(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().endswith("ok")
+
+
+@pytest.mark.gpu
+def test_search_cap_bounds_the_write_while_another_thread_grows_the_index(tmp_path):
+    """tests/native/search_cap_race.c: buffers sized from an earlier vl_index_len(), a second thread adding rows the
+    whole time; vl_index_search_cap never writes past the caller's capacity (single-GPU and row-sharded handle)."""
+    from vectorlite_amd import _lib
+    libdir = os.path.dirname(_lib.SO_PATH)
+    exe = tmp_path / "search_cap_race"
+    subprocess.check_call(["gcc", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "search_cap_race.c"), "-L", libdir, "-lvectorlite_amd",
+                           "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined", "-lpthread", "-lm", "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().endswith("ok"), r.stdout

@@ -14,7 +14,7 @@ RUST_TO_C = {
     "*const c_char": "const char *", "": "void",
     "*const vl_vlc_doc": "const vl_vlc_doc *", "*mut vl_vlc_doc": "vl_vlc_doc *", "*mut *mut vl_vlc_doc": "vl_vlc_doc **",
     "*const vl_comm": "const vl_comm *", "*mut vl_comm": "vl_comm *", "*mut *mut vl_comm": "vl_comm **",
-    "*const u8": "const uint8_t *", "*mut u8": "uint8_t *",
+    "*const u8": "const uint8_t *", "*mut u8": "uint8_t *", "*const c_int": "const int *", "*mut c_int": "int *",
 }
 
 

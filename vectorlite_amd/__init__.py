@@ -26,7 +26,7 @@ import numpy as np
 from . import _lib
 
 __all__ = [
-    "SimilarityMetric", "Vector", "SearchResult", "FlatIndex", "HNSWIndex", "VectorLiteError", "DimensionMismatch",
+    "SimilarityMetric", "Vector", "SearchResult", "FlatIndex", "MultiFlatIndex", "HNSWIndex", "VectorLiteError", "DimensionMismatch",
     "MetricMismatch", "NaNScore", "DeviceError", "IndexOpError", "hnsw_score", "runtime_info",
     "PATH_FAST", "PATH_EXACT_SELECT", "PATH_EXACT_SORT",
 ]
@@ -485,6 +485,47 @@ class FlatIndex:
         n, ms, b = C.c_uint64(0), C.c_double(0.0), C.c_uint64(0)
         _raise(self._L.vl_index_profile_read(self._h, C.byref(n), C.byref(ms), C.byref(b)))
         return n.value, ms.value, b.value
+
+
+class MultiFlatIndex(FlatIndex):
+    """ONE flat index over several GPUs in one process (vl_flat_create_multi): the same `VectorIndex` surface as
+    `FlatIndex`, every method inherited -- only the handle differs.  mode "replicas": every GPU holds every row,
+    concurrent searches are dealt to the least busy replica, batches are cut across them.  mode "row_shards": every
+    GPU holds part of the rows, every search runs on all of them and the exact per-shard top-k are merged on the
+    device, bit-identical to one index holding every row.  A device listed twice = two parts on that card."""
+
+    REPLICAS, ROW_SHARDS = 0, 1
+
+    def __init__(self, dim: int, devices: Sequence[int], mode="replicas"):
+        m = {"replicas": 0, "row_shards": 1}.get(mode, mode)
+        if m not in (0, 1):
+            raise ValueError("mode must be 'replicas' or 'row_shards'")
+        L = _lib.load()
+        devs = [int(d) for d in devices]
+        arr = (C.c_int * max(len(devs), 1))(*devs)
+        h = C.c_void_p()
+        _raise(L.vl_flat_create_multi(int(dim), arr, len(devs), int(m), C.byref(h)))
+        super().__init__(dim, device=devs[0] if devs else 0, _handle=h)
+        self.devices = devs
+        self.mode = int(m)
+
+    def parts(self) -> Dict[str, Any]:
+        """Rows held and searches answered by each part (vl_index_parts)."""
+        n, mode = C.c_int(0), C.c_int(0)
+        _raise(self._L.vl_index_parts(self._h, C.byref(n), C.byref(mode), None, None, 0))
+        rows = np.zeros(max(n.value, 1), dtype=np.uint64)
+        srch = np.zeros(max(n.value, 1), dtype=np.uint64)
+        _raise(self._L.vl_index_parts(self._h, C.byref(n), C.byref(mode), _pu64(rows), _pu64(srch), int(n.value)))
+        return {"n_parts": int(n.value), "mode": int(mode.value), "rows": rows[: n.value].tolist(), "searches": srch[: n.value].tolist()}
+
+    def clone(self) -> "MultiFlatIndex":
+        h = C.c_void_p()
+        _raise(self._L.vl_index_clone(self._h, C.byref(h)))
+        c = MultiFlatIndex.__new__(MultiFlatIndex)
+        FlatIndex.__init__(c, self.dimension(), device=self.device, _handle=h)
+        c.devices, c.mode = list(self.devices), self.mode
+        c._meta = dict(self._meta)
+        return c
 
 
 class HNSWIndex:

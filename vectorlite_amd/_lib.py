@@ -15,7 +15,7 @@ SO_PATH = os.environ.get("VL_LIB_PATH") or os.path.join(_HERE, "libvectorlite_am
 
 # every symbol include/vectorlite_amd.h declares
 SYMBOLS = [
-    "vl_flat_create", "vl_flat_from_rows", "vl_hnsw_create", "vl_hnsw_create_ex", "vl_index_type", "vl_index_metric", "vl_index_search_ef", "vl_index_clone", "vl_index_destroy", "vl_index_reserve",
+    "vl_flat_create", "vl_flat_from_rows", "vl_flat_create_multi", "vl_index_parts", "vl_hnsw_create", "vl_hnsw_create_ex", "vl_index_type", "vl_index_metric", "vl_index_search_ef", "vl_index_clone", "vl_index_destroy", "vl_index_reserve",
     "vl_index_add", "vl_index_add_bulk", "vl_index_add_embeddings_f32", "vl_index_delete", "vl_index_search", "vl_index_search_batch", "vl_index_search_cap", "vl_index_search_batch_cap",
     "vl_index_len", "vl_index_is_empty", "vl_index_dimension", "vl_index_get_vector", "vl_index_max_id",
     "vl_index_export", "vl_index_search_positions", "vl_index_search_batch_positions", "vl_index_search_batch_dev", "vl_index_search_batch_embeddings_f32", "vl_index_hnsw_distances", "vl_hnsw_score",
@@ -58,6 +58,8 @@ def load() -> C.CDLL:
 
     sig("vl_flat_create", i32, [u64, i32, pp])
     sig("vl_flat_from_rows", i32, [u64, p_u64, p_f64, u64, i32, pp])
+    sig("vl_flat_create_multi", i32, [u64, p_i32, i32, i32, pp])
+    sig("vl_index_parts", i32, [vp, p_i32, p_i32, p_u64, p_u64, i32])
     sig("vl_hnsw_create", i32, [u64, i32, i32, pp])
     sig("vl_hnsw_create_ex", i32, [u64, i32, C.c_uint32, C.c_uint32, C.c_uint32, u64, i32, pp])
     sig("vl_index_type", i32, [vp])

@@ -21,7 +21,7 @@ ARCH = "gfx950"
 # -ffp-contract=off: the exact kernels must round every multiply and every add separately, in the
 # reference's order (src/lib.rs:425-572); the f32 scan spells its FMAs out with fmaf().
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", f"-I{INCLUDE}"]
-SOURCES = ["kernels.hip", "hnsw.hip", "mfma_scan.hip", "shard.hip", "flat_index.cpp", "hnsw_index.cpp", "shard_comm.cpp",
+SOURCES = ["kernels.hip", "hnsw.hip", "mfma_scan.hip", "shard.hip", "flat_index.cpp", "multi_index.cpp", "hnsw_index.cpp", "shard_comm.cpp",
            "vlc_loader.cpp", "c_api.cpp"]
 # RCCL (the row-shard all-gather, shard_comm.cpp): the ROCm copy; in a process that has imported torch the loader
 # resolves the same SONAME (librccl.so.1) to the copy torch already mapped, so there is one RCCL per process

@@ -7,15 +7,17 @@
 
 #include "flat_index.hpp"
 #include "hnsw_index.hpp"
+#include "multi_index.hpp"
 #include "shard.hpp"
 #include "vlc_loader.hpp"
 
 // enum VectorIndexWrapper { Flat(FlatIndex), HNSW(Box<HNSWIndex>) } (src/lib.rs:271-276): exactly one
-// of the two pointers is set; the vl_index_* entry points dispatch like the wrapper's impl
+// of the pointers is set; the vl_index_* entry points dispatch like the wrapper's impl
 // (src/lib.rs:278-327).
 struct vl_index {
     vl::GpuFlatIndex* flat;
     vl::HnswIndex* hnsw;
+    vl::MultiFlatIndex* multi;  // a flat index over several GPUs (multi_index.hpp): behaves as VectorIndexWrapper::Flat
 };
 
 // one rank's end of the RCCL communicator of a row-sharded index (shard.hpp)
@@ -43,9 +45,16 @@ int guarded(F&& f)
     }
 }
 
+// the flat flavours share one method surface (GpuFlatIndex / MultiFlatIndex): f is a generic lambda
+template <typename F>
+int on_flat(const vl_index* h, F&& f)
+{
+    return h->multi ? f(h->multi) : f(h->flat);
+}
+
 int wrap(vl::GpuFlatIndex* idx, vl_index** out)
 {
-    vl_index* h = new (std::nothrow) vl_index{idx, nullptr};
+    vl_index* h = new (std::nothrow) vl_index{idx, nullptr, nullptr};
     if (!h) {
         delete idx;
         return VL_ERR_OOM;
@@ -87,6 +96,43 @@ int vl_flat_from_rows(uint64_t dim, const uint64_t* ids, const double* values, u
     });
 }
 
+int vl_flat_create_multi(uint64_t dim, const int* device_ids, int n_dev, int mode, vl_index** out)
+{
+    return guarded([&]() -> int {
+        if (!out) return VL_ERR_INVALID_ARG;
+        *out = nullptr;
+        vl::MultiFlatIndex* m = nullptr;
+        const int rc = vl::MultiFlatIndex::create(dim, device_ids, n_dev, mode, &m);
+        if (rc != VL_OK) return rc;
+        vl_index* h = new (std::nothrow) vl_index{nullptr, nullptr, m};
+        if (!h) {
+            delete m;
+            return VL_ERR_OOM;
+        }
+        *out = h;
+        return VL_OK;
+    });
+}
+
+int vl_index_parts(const vl_index* h, int* n_parts, int* mode, uint64_t* rows, uint64_t* searches, int capacity)
+{
+    if (!h) return VL_ERR_INVALID_ARG;
+    if (!h->multi) {  // a single-GPU handle is one part
+        if (n_parts) *n_parts = 1;
+        if (mode) *mode = -1;
+        if (capacity >= 1) {
+            if (rows) rows[0] = vl_index_len(h);
+            if (searches) searches[0] = 0;
+        }
+        return VL_OK;
+    }
+    const int P = h->multi->n_parts();
+    if (n_parts) *n_parts = P;
+    if (mode) *mode = h->multi->mode();
+    if (capacity >= P) h->multi->part_stats(rows, searches);
+    return VL_OK;
+}
+
 int vl_hnsw_create_ex(uint64_t dim, int metric, uint32_t m, uint32_t m0, uint32_t ef_construction, uint64_t seed,
                       int device, vl_index** out)
 {
@@ -101,7 +147,7 @@ int vl_hnsw_create_ex(uint64_t dim, int metric, uint32_t m, uint32_t m0, uint32_
         vl::HnswIndex* idx = nullptr;
         int rc = vl::HnswIndex::create(dim, metric, p, device, &idx);
         if (rc != VL_OK) return rc;
-        vl_index* h = new (std::nothrow) vl_index{nullptr, idx};
+        vl_index* h = new (std::nothrow) vl_index{nullptr, idx, nullptr};
         if (!h) {
             delete idx;
             return VL_ERR_OOM;
@@ -119,7 +165,7 @@ int vl_hnsw_create(uint64_t dim, int metric, int device, vl_index** out)
 
 #define VL_FLAT_ONLY(h)                                                         \
     if (!(h) || !(h)->flat) {                                                   \
-        vl::set_last_error("this entry point needs a flat index handle");       \
+        vl::set_last_error("this entry point needs a single-GPU flat index handle"); \
         return VL_ERR_INVALID_ARG;                                              \
     }
 
@@ -132,9 +178,21 @@ int vl_index_clone(const vl_index* h, vl_index** out)
             vl::HnswIndex* hc = nullptr;
             int rc = h->hnsw->clone(&hc);
             if (rc != VL_OK) return rc;
-            vl_index* w = new (std::nothrow) vl_index{nullptr, hc};
+            vl_index* w = new (std::nothrow) vl_index{nullptr, hc, nullptr};
             if (!w) {
                 delete hc;
+                return VL_ERR_OOM;
+            }
+            *out = w;
+            return VL_OK;
+        }
+        if (h->multi) {
+            vl::MultiFlatIndex* mc = nullptr;
+            int rc = h->multi->clone(&mc);
+            if (rc != VL_OK) return rc;
+            vl_index* w = new (std::nothrow) vl_index{nullptr, nullptr, mc};
+            if (!w) {
+                delete mc;
                 return VL_ERR_OOM;
             }
             *out = w;
@@ -153,6 +211,7 @@ void vl_index_destroy(vl_index* h)
     try {
         delete h->flat;
         delete h->hnsw;
+        delete h->multi;
     } catch (...) {
     }
     delete h;
@@ -162,8 +221,8 @@ int vl_index_reserve(vl_index* h, uint64_t n_rows)
 {
     return guarded([&]() -> int {
         if (h && h->hnsw) return VL_OK;  // the graph grows on demand
-        VL_FLAT_ONLY(h);
-        return h->flat->reserve(n_rows);
+        if (!h) return VL_ERR_INVALID_ARG;
+        return on_flat(h, [&](auto* f) { return f->reserve(n_rows); });
     });
 }
 
@@ -171,7 +230,8 @@ int vl_index_add(vl_index* h, uint64_t id, const double* values, uint64_t len)
 {
     return guarded([&]() -> int {
         if (!h) return VL_ERR_INVALID_ARG;
-        return h->hnsw ? h->hnsw->add(id, values, len) : h->flat->add(id, values, len);
+        if (h->hnsw) return h->hnsw->add(id, values, len);
+        return on_flat(h, [&](auto* f) { return f->add(id, values, len); });
     });
 }
 
@@ -181,7 +241,7 @@ int vl_index_add_bulk(vl_index* h, const uint64_t* ids, const double* values, ui
     return guarded([&]() -> int {
         if (!h) return VL_ERR_INVALID_ARG;
         if (h->hnsw) return h->hnsw->add_bulk(ids, values, n, values_on_device != 0);  // HNSW add always validates
-        return h->flat->add_bulk(ids, values, n, validate != 0, values_on_device != 0);
+        return on_flat(h, [&](auto* f) { return f->add_bulk(ids, values, n, validate != 0, values_on_device != 0); });
     });
 }
 
@@ -196,11 +256,12 @@ int vl_index_add_embeddings_f32(vl_index* h, const uint64_t* ids, const float* e
                                           [&](const uint64_t* i, const double* rows, uint64_t c) {
                                               return h->hnsw->add_bulk(i, rows, c, true);
                                           });
-        return vl::add_embeddings_f32(h->flat->device(), h->flat->dimension(), ids, embeddings, n, normalize != 0,
-                                      embeddings_on_device != 0,
-                                      [&](const uint64_t* i, const double* rows, uint64_t c) {
-                                          return h->flat->add_bulk(i, rows, c, validate != 0, true);
-                                      });
+        return on_flat(h, [&](auto* f) {
+            return vl::add_embeddings_f32(f->device(), f->dimension(), ids, embeddings, n, normalize != 0, embeddings_on_device != 0,
+                                          [&](const uint64_t* i, const double* rows, uint64_t c) {
+                                              return f->add_bulk(i, rows, c, validate != 0, true);
+                                          });
+        });
     });
 }
 
@@ -208,7 +269,8 @@ int vl_index_delete(vl_index* h, uint64_t id)
 {
     return guarded([&]() -> int {
         if (!h) return VL_ERR_INVALID_ARG;
-        return h->hnsw ? h->hnsw->remove(id) : h->flat->remove(id);
+        if (h->hnsw) return h->hnsw->remove(id);
+        return on_flat(h, [&](auto* f) { return f->remove(id); });
     });
 }
 
@@ -218,8 +280,8 @@ int vl_index_search(const vl_index* h, const double* query, uint64_t q_len, uint
     return guarded([&]() -> int {
         if (!h || !out_n) return VL_ERR_INVALID_ARG;
         if (h->hnsw) return h->hnsw->search(query, q_len, k, metric, 0, out_ids, out_scores, out_n);
-        if (!out_ids && k != 0 && h->flat->len() != 0) return VL_ERR_INVALID_ARG;
-        return h->flat->search(query, q_len, k, metric, nullptr, out_ids, out_scores, out_n);
+        if (!out_ids && k != 0 && vl_index_len(h) != 0) return VL_ERR_INVALID_ARG;
+        return on_flat(h, [&](auto* f) { return f->search(query, q_len, k, metric, nullptr, out_ids, out_scores, out_n); });
     });
 }
 
@@ -240,12 +302,12 @@ int vl_index_search_batch_cap(const vl_index* h, const double* queries, uint64_t
         if (!h || (!out_n && nq)) return VL_ERR_INVALID_ARG;
         if (nq == 0) return VL_OK;
         // k < out_stride: answer into [nq, kk] scratch (kk = min(k, len): nothing larger is ever written) and spread the rows
-        const uint64_t len = h->hnsw ? h->hnsw->len() : h->flat->len();
+        const uint64_t len = vl_index_len(h);
         const uint64_t kk = k < len ? k : len;
         std::vector<uint64_t> ids(nq * kk);
         std::vector<double> scores(nq * kk);
         const int rc = h->hnsw ? h->hnsw->search_batch(queries, nq, q_len, kk, metric, 0, ids.data(), scores.data(), out_n)
-                               : h->flat->search_batch(queries, nq, q_len, kk, metric, nullptr, ids.data(), scores.data(), out_n);
+                               : on_flat(h, [&](auto* f) { return f->search_batch(queries, nq, q_len, kk, metric, nullptr, ids.data(), scores.data(), out_n); });
         if (rc != VL_OK) return rc;
         for (uint64_t q = 0; q < nq; ++q) {
             const uint64_t m = out_n[q] < kk ? out_n[q] : kk;
@@ -262,9 +324,12 @@ int vl_index_search_positions(const vl_index* h, const double* query, uint64_t q
                               uint64_t* out_pos, uint64_t* out_ids, double* out_scores, uint64_t* out_n)
 {
     return guarded([&]() -> int {
-        VL_FLAT_ONLY(h);
+        if (!h || h->hnsw) {
+            vl::set_last_error("storage positions are a flat-index notion");
+            return VL_ERR_INVALID_ARG;
+        }
         if (!out_n) return VL_ERR_INVALID_ARG;
-        return h->flat->search(query, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
+        return on_flat(h, [&](auto* f) { return f->search(query, q_len, k, metric, out_pos, out_ids, out_scores, out_n); });
     });
 }
 
@@ -274,7 +339,7 @@ int vl_index_search_batch(const vl_index* h, const double* queries, uint64_t nq,
     return guarded([&]() -> int {
         if (!h || (!out_n && nq)) return VL_ERR_INVALID_ARG;
         if (h->hnsw) return h->hnsw->search_batch(queries, nq, q_len, k, metric, 0, out_ids, out_scores, out_n);
-        return h->flat->search_batch(queries, nq, q_len, k, metric, nullptr, out_ids, out_scores, out_n);
+        return on_flat(h, [&](auto* f) { return f->search_batch(queries, nq, q_len, k, metric, nullptr, out_ids, out_scores, out_n); });
     });
 }
 
@@ -283,9 +348,12 @@ int vl_index_search_batch_positions(const vl_index* h, const double* queries, ui
                                     double* out_scores, uint64_t* out_n)
 {
     return guarded([&]() -> int {
-        VL_FLAT_ONLY(h);
+        if (!h || h->hnsw) {
+            vl::set_last_error("storage positions are a flat-index notion");
+            return VL_ERR_INVALID_ARG;
+        }
         if (!out_n && nq) return VL_ERR_INVALID_ARG;
-        return h->flat->search_batch(queries, nq, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
+        return on_flat(h, [&](auto* f) { return f->search_batch(queries, nq, q_len, k, metric, out_pos, out_ids, out_scores, out_n); });
     });
 }
 
@@ -296,15 +364,15 @@ int vl_index_search_batch_embeddings_f32(const vl_index* h, const float* embeddi
     return guarded([&]() -> int {
         if (!h || (!out_n && nq)) return VL_ERR_INVALID_ARG;
         for (uint64_t i = 0; i < nq; ++i) out_n[i] = 0;
-        const uint64_t want = h->hnsw ? h->hnsw->dimension() : h->flat->dimension();
-        const bool empty_flat = !h->hnsw && h->flat->len() == 0;  // src/index/flat.rs:99: an empty flat index accepts any length
+        const uint64_t want = vl_index_dimension(h);
+        const bool empty_flat = !h->hnsw && vl_index_len(h) == 0;  // src/index/flat.rs:99: an empty flat index accepts any length
         if (dim != want && !empty_flat) {
             vl::set_dim_mismatch(want, dim);
             vl::set_last_error("Dimension mismatch: expected " + std::to_string(want) + ", got " + std::to_string(dim));
             return VL_ERR_DIM_MISMATCH;
         }
         if (nq == 0 || empty_flat) return VL_OK;
-        const int device = h->hnsw ? h->hnsw->device() : h->flat->device();
+        const int device = h->hnsw ? h->hnsw->device() : (h->multi ? h->multi->device() : h->flat->device());
         return vl::search_embeddings_f32(device, dim, embeddings, nq, normalize != 0, embeddings_on_device != 0,
                                          [&](const double* d_q, uint64_t n) -> int {
                                              return vl_index_search_batch_dev(h, d_q, n, dim, k, metric, nullptr, out_ids, out_scores, out_n);
@@ -334,7 +402,7 @@ int vl_index_search_batch_dev(const vl_index* h, const double* d_queries, uint64
             const double* hp = !d_queries ? nullptr : (hq.empty() ? &never_read : hq.data());
             return h->hnsw->search_batch(hp, nq, q_len, k, metric, 0, out_ids, out_scores, out_n);
         }
-        return h->flat->search_batch_device(d_queries, nq, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
+        return on_flat(h, [&](auto* f) { return f->search_batch_device(d_queries, nq, q_len, k, metric, out_pos, out_ids, out_scores, out_n); });
     });
 }
 
@@ -470,11 +538,11 @@ int vl_shard_merge(int device, const uint64_t* gathered, uint32_t world, uint64_
     });
 }
 
-uint64_t vl_index_len(const vl_index* h) { return !h ? 0 : (h->hnsw ? h->hnsw->len() : h->flat->len()); }
+uint64_t vl_index_len(const vl_index* h) { return !h ? 0 : (h->hnsw ? h->hnsw->len() : (h->multi ? h->multi->len() : h->flat->len())); }
 int vl_index_is_empty(const vl_index* h) { return vl_index_len(h) == 0; }
 uint64_t vl_index_dimension(const vl_index* h)
 {
-    return !h ? 0 : (h->hnsw ? h->hnsw->dimension() : h->flat->dimension());
+    return !h ? 0 : (h->hnsw ? h->hnsw->dimension() : (h->multi ? h->multi->dimension() : h->flat->dimension()));
 }
 
 // VectorIndexWrapper::index_type / ::metric (src/lib.rs:329-346): Flat -> (0, None), HNSW -> (1, Some(m)).
@@ -503,7 +571,8 @@ int vl_index_get_vector(const vl_index* h, uint64_t id, double* out_values)
 {
     return guarded([&]() -> int {
         if (!h || !out_values) return VL_ERR_INVALID_ARG;
-        return h->hnsw ? h->hnsw->get_vector(id, out_values) : h->flat->get_vector(id, out_values);
+        if (h->hnsw) return h->hnsw->get_vector(id, out_values);
+        return on_flat(h, [&](auto* f) { return f->get_vector(id, out_values); });
     });
 }
 
@@ -511,7 +580,8 @@ int vl_index_max_id(const vl_index* h, uint64_t* out_id)
 {
     return guarded([&]() -> int {
         if (!h || !out_id) return VL_ERR_INVALID_ARG;
-        return h->hnsw ? h->hnsw->max_id(out_id) : h->flat->max_id(out_id);
+        if (h->hnsw) return h->hnsw->max_id(out_id);
+        return on_flat(h, [&](auto* f) { return f->max_id(out_id); });
     });
 }
 
@@ -520,7 +590,7 @@ int vl_index_export(const vl_index* h, uint64_t* out_ids, double* out_values)
     return guarded([&]() -> int {
         if (!h) return VL_ERR_INVALID_ARG;
         if (h->hnsw) return h->hnsw->export_rows(out_ids, out_values);
-        return h->flat->export_rows(out_ids, out_values);
+        return on_flat(h, [&](auto* f) { return f->export_rows(out_ids, out_values); });
     });
 }
 
@@ -600,7 +670,7 @@ int vl_vlc_build_index(const vl_vlc_doc* doc, int device, vl_index** out)
         vl::HnswIndex* hn = nullptr;
         const int rc = vl::vlc_build_index(doc->d, device, &f, &hn);
         if (rc != VL_OK) return rc;
-        vl_index* h = new (std::nothrow) vl_index{f, hn};
+        vl_index* h = new (std::nothrow) vl_index{f, hn, nullptr};
         if (!h) {
             delete f;
             delete hn;
@@ -617,23 +687,21 @@ int vl_last_path(void) { return vl::last_path(); }
 
 int vl_index_force_path(vl_index* h, int path)
 {
-    if (!h || !h->flat || (path != 0 && path != VL_PATH_EXACT_SELECT && path != VL_PATH_EXACT_SORT)) return VL_ERR_INVALID_ARG;
-    h->flat->force_path(path);
-    return VL_OK;
+    if (!h || h->hnsw || (path != 0 && path != VL_PATH_EXACT_SELECT && path != VL_PATH_EXACT_SORT)) return VL_ERR_INVALID_ARG;
+    return on_flat(h, [&](auto* f) { f->force_path(path); return (int)VL_OK; });
 }
 
 int vl_index_set_single_filter(vl_index* h, int mode)
 {
-    if (!h || !h->flat || (mode != 0 && mode != 1)) return VL_ERR_INVALID_ARG;
-    h->flat->set_single_filter(mode);
-    return VL_OK;
+    if (!h || h->hnsw || (mode != 0 && mode != 1)) return VL_ERR_INVALID_ARG;
+    return on_flat(h, [&](auto* f) { f->set_single_filter(mode); return (int)VL_OK; });
 }
 
 int vl_index_set_coalescing(vl_index* h, int max_batch, int window_us)
 {
     if (!h || max_batch < 0 || window_us < 0) return VL_ERR_INVALID_ARG;
     if (h->hnsw) h->hnsw->set_coalescing(max_batch, window_us);
-    else h->flat->set_coalescing(max_batch, window_us);
+    else on_flat(h, [&](auto* f) { f->set_coalescing(max_batch, window_us); return (int)VL_OK; });
     return VL_OK;
 }
 
@@ -641,7 +709,7 @@ int vl_index_coalesce_stats(const vl_index* h, uint64_t* batches, uint64_t* quer
 {
     if (!h) return VL_ERR_INVALID_ARG;
     if (h->hnsw) h->hnsw->coalesce_stats(batches, queries);
-    else h->flat->coalesce_stats(batches, queries);
+    else on_flat(h, [&](auto* f) { f->coalesce_stats(batches, queries); return (int)VL_OK; });
     return VL_OK;
 }
 
@@ -687,23 +755,20 @@ int vl_index_hnsw_walk_stats(const vl_index* h, uint64_t* queries, uint64_t* dis
 
 int vl_index_last_scan(const vl_index* h, int* variant, int* grid, int* query_in_kernarg)
 {
-    VL_FLAT_ONLY(h);
-    h->flat->last_scan(variant, grid, query_in_kernarg);
-    return VL_OK;
+    if (!h || h->hnsw) return VL_ERR_INVALID_ARG;
+    return on_flat(h, [&](auto* f) { f->last_scan(variant, grid, query_in_kernarg); return (int)VL_OK; });
 }
 
 int vl_index_profile_enable(vl_index* h, int enable)
 {
-    if (!h || !h->flat) return VL_ERR_INVALID_ARG;
-    h->flat->profile_enable(enable != 0);
-    return VL_OK;
+    if (!h || h->hnsw) return VL_ERR_INVALID_ARG;
+    return on_flat(h, [&](auto* f) { f->profile_enable(enable != 0); return (int)VL_OK; });
 }
 
 int vl_index_profile_read(vl_index* h, uint64_t* n_scan_launches, double* scan_ms_total, uint64_t* scan_bytes_total)
 {
-    if (!h || !h->flat) return VL_ERR_INVALID_ARG;
-    h->flat->profile_read(n_scan_launches, scan_ms_total, scan_bytes_total);
-    return VL_OK;
+    if (!h || h->hnsw) return VL_ERR_INVALID_ARG;
+    return on_flat(h, [&](auto* f) { f->profile_read(n_scan_launches, scan_ms_total, scan_bytes_total); return (int)VL_OK; });
 }
 
 int vl_runtime_info(int* n_devices, int* abi_version)

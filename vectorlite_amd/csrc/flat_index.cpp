@@ -320,7 +320,7 @@ int GpuFlatIndex::add(uint64_t id, const double* values, uint64_t len)
 }
 
 int GpuFlatIndex::add_bulk(const uint64_t* ids, const double* values, uint64_t n, bool validate,
-                           bool values_on_device)
+                           bool values_on_device, int src_device)
 {
     if (n == 0) return OK;
     if (!ids || (!values && dim_)) return ERR_INVALID_ARG;
@@ -349,9 +349,13 @@ int GpuFlatIndex::add_bulk(const uint64_t* ids, const double* values, uint64_t n
     const uint64_t first = ids_.size();
     int rc = ensure_capacity(first + n_take);
     if (rc == OK && dim_) {
-        hipError_t e = hipMemcpyAsync(d_master_ + first * dim_, values, n_take * dim_ * sizeof(double),
-                                      values_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                                      mut_stream_);
+        hipError_t e;
+        if (values_on_device && src_device >= 0 && src_device != device_)
+            e = hipMemcpyPeerAsync(d_master_ + first * dim_, device_, values, src_device, n_take * dim_ * sizeof(double),
+                                   mut_stream_);
+        else
+            e = hipMemcpyAsync(d_master_ + first * dim_, values, n_take * dim_ * sizeof(double),
+                               values_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, mut_stream_);
         if (e != hipSuccess) {
             set_last_error(std::string("hipMemcpyAsync(rows): ") + hipGetErrorString(e));
             rc = ERR_DEVICE;
@@ -406,7 +410,38 @@ int GpuFlatIndex::remove_position(uint64_t pos)
     return OK;
 }
 
-int GpuFlatIndex::remove(uint64_t id)
+int GpuFlatIndex::remove(uint64_t id) { return remove_report(id, nullptr); }
+
+bool GpuFlatIndex::contains(uint64_t id) const
+{
+    std::unique_lock<std::shared_mutex> lk(mu_);  // may rebuild the table
+    if (!id_counts_valid_) rebuild_id_counts();
+    auto it = id_counts_.find(id);
+    return it != id_counts_.end() && it->second > 0;
+}
+
+int GpuFlatIndex::find_first(uint64_t id, uint64_t* out_pos) const
+{
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    auto it = std::find(ids_.begin(), ids_.end(), id);
+    if (it == ids_.end()) return ERR_NOT_FOUND;
+    if (out_pos) *out_pos = (uint64_t)(it - ids_.begin());
+    return OK;
+}
+
+int GpuFlatIndex::get_row_at(uint64_t pos, double* out) const
+{
+    if (!out && dim_) return ERR_INVALID_ARG;
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    if (pos >= ids_.size()) return ERR_NOT_FOUND;
+    if (dim_) {
+        VL_HIP(hipSetDevice(device_));
+        VL_HIP(hipMemcpy(out, d_master_ + pos * dim_, dim_ * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return OK;
+}
+
+int GpuFlatIndex::remove_report(uint64_t id, std::vector<uint64_t>* removed_positions)
 {
     std::unique_lock<std::shared_mutex> lk(mu_);
     VL_HIP(hipSetDevice(device_));
@@ -414,6 +449,7 @@ int GpuFlatIndex::remove(uint64_t id)
     for (uint64_t p = ids_.size(); p-- > 0;) {
         if (ids_[p] == id) {
             VL_TRY(remove_position(p));
+            if (removed_positions) removed_positions->push_back(p);
             if (id_counts_valid_) {
                 auto it = id_counts_.find(id);
                 if (it != id_counts_.end() && it->second > 0) --it->second;

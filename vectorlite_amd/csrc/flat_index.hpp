@@ -110,8 +110,16 @@ public:
 
     // trait VectorIndex (src/lib.rs:224-245)
     int add(uint64_t id, const double* values, uint64_t len);
-    int add_bulk(const uint64_t* ids, const double* values, uint64_t n, bool validate, bool values_on_device);
+    // values_on_device: `values` is device memory; src_device >= 0 names the GPU it lives on when that is not this
+    // index's own (a multi-GPU handle replicating rows: hipMemcpyPeerAsync)
+    int add_bulk(const uint64_t* ids, const double* values, uint64_t n, bool validate, bool values_on_device,
+                 int src_device = -1);
     int remove(uint64_t id);  // `delete`
+    // the same, reporting which storage positions went (descending) -- a sharded handle keeps a per-row table beside this index
+    int remove_report(uint64_t id, std::vector<uint64_t>* removed_positions);
+    bool contains(uint64_t id) const;                       // O(1) after the first call (the duplicate-id table)
+    int find_first(uint64_t id, uint64_t* out_pos) const;   // first row with that id (get_vector's rule); ERR_NOT_FOUND
+    int get_row_at(uint64_t pos, double* out) const;
     int search(const double* query, uint64_t q_len, uint64_t k, int metric, uint64_t* out_pos,
                uint64_t* out_ids, double* out_scores, uint64_t* out_n) const;
     // NEW (no reference counterpart): nq independent searches sharing slab passes; outputs are

@@ -645,7 +645,6 @@ __global__ __launch_bounds__(1024) void k_merge_finalize(const Cand32* __restric
         // rank = how many candidates stand in front of this one: every candidate sits in a lane of this wave, so
         // entry j is read with v_readlane (a scalar operand of the compares), no LDS round trip per entry
         int rank = 0;
-#pragma unroll 8
         for (int j = 0; j < n_cand; ++j) {
             const double sj = read_lane(sc, j);
             const uint32_t pj = read_lane(my_pos, j);

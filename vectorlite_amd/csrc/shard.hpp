@@ -45,7 +45,8 @@ hipError_t launch_shard_merge(hipStream_t stream, const unsigned long long* gath
 // non-empty index still rejects a query of the wrong length, like one index holding all rows would).
 void shard_search_local(const GpuFlatIndex* shard, uint64_t row_offset, uint64_t expected_len, bool any_rows,
                         const double* queries, uint64_t nq, uint64_t q_len, uint64_t ks, int metric,
-                        unsigned long long* packed, bool queries_on_device = false);  // queries: host, or this GPU's memory
+                        unsigned long long* packed, bool queries_on_device = false,  // queries: host, or this GPU's memory
+                        const uint64_t* pos_to_global = nullptr);  // shards that are not one contiguous range: a table instead of the offset
 
 // Device buffers + stream for gather/merge on one GPU.
 class ShardMerger {

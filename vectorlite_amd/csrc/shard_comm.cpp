@@ -40,7 +40,7 @@ static_assert(sizeof(unsigned long long) == sizeof(uint64_t) && sizeof(double) =
 // ---------------------------------------------------------------------------------------------------------
 void shard_search_local(const GpuFlatIndex* shard, uint64_t row_offset, uint64_t expected_len, bool any_rows,
                         const double* queries, uint64_t nq, uint64_t q_len, uint64_t ks, int metric,
-                        unsigned long long* packed, bool queries_on_device)
+                        unsigned long long* packed, bool queries_on_device, const uint64_t* pos_to_global)
 {
     const uint64_t words = shard_packed_words(nq, ks), plane = nq * ks;
     std::memset(packed, 0, words * sizeof(unsigned long long));
@@ -81,7 +81,10 @@ void shard_search_local(const GpuFlatIndex* shard, uint64_t row_offset, uint64_t
         }
         if (status == OK) {
             for (uint64_t q = 0; q < nq; ++q)
-                for (uint64_t j = 0; j < cnt[q]; ++j) gp[q * ks + j] += row_offset;  // local -> global position
+                for (uint64_t j = 0; j < cnt[q]; ++j) {  // local -> global position
+                    unsigned long long& g = gp[q * ks + j];
+                    g = pos_to_global ? pos_to_global[g] : g + row_offset;
+                }
         } else {
             std::memset(cnt, 0, (nq + 3 * plane) * sizeof(unsigned long long));  // a failed shard offers nothing
         }
