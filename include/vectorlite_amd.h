@@ -189,14 +189,15 @@ int vl_index_metric(const vl_index *h, int *out_metric);
 
 /* HNSW only, own extension (the reference has no ef knob): nq walks with beam width
  * max(ef, min(k, len)); outputs as vl_index_search_batch.  ef = 0 is what vl_index_search does: the reference's
- * ef = min(k, len) (src/index/hnsw.rs:437,454) raised to the handle's beam floor (below). */
+ * ef = min(k, len) (src/index/hnsw.rs:437,454), raised to the handle's beam floor only if the caller set one (below). */
 int vl_index_search_ef(const vl_index *h, const double *queries, uint64_t nq, uint64_t q_len, uint64_t k,
                        uint32_t ef, int metric, uint64_t *out_ids, double *out_scores, uint64_t *out_n);
 
-/* HNSW handle: beam floor of searches that name no ef.  The reference walks with ef = min(k, len) -- 10 entries for
- * k = 10; this library's walk keeps at least `min_beam` entries (default 32, at most 128) and returns the best
- * min(k, len) of them: the same number of results, recall@10 0.96 instead of 0.78 at N = 1 M on embedding-like data.
- * 0 = the strict reference rule. */
+/* HNSW handle: OPT-IN beam floor of searches that name no ef.  DEFAULT 0 = the reference's rule: the walk keeps
+ * ef = min(k, len) entries (src/index/hnsw.rs:437) -- 10 for k = 10.  With min_beam > 0 (at most 128) the walk keeps at
+ * least that many entries and returns the best min(k, len) of them: the same number of results, recall@10 0.96
+ * instead of 0.78 at N = 1 M on embedding-like data with min_beam = 32.  That is a DEVIATION from the reference's walk
+ * width, which is why it is off unless asked for (env VL_HNSW_MIN_BEAM sets it for handles created afterwards). */
 int vl_index_hnsw_set_min_beam(vl_index *h, uint32_t min_beam);
 
 /* HNSW handle: the graph as it stands, every node (tombstoned ones included; node = insertion position).  level[n]

@@ -51,7 +51,7 @@ def test_config4_hnsw_1m_x_384_recall_against_exact_and_cpu_walk():
         return float(np.mean([sum(1 for x in ids_rows[i] if D[i][int(x)] <= kth[i]) / float(k) for i in range(n_truth)]))
 
     out = {}
-    for name, beam, ef in (("strict_ef10", 0, 0), ("default_floor32", 32, 0), ("ef128", 32, 128)):
+    for name, beam, ef in (("strict_ef10", 0, 0), ("floor32_optin", 32, 0), ("ef128", 32, 128)):
         hn.set_min_beam(beam)
         hn.search_batch(Q[:8], k, 0, ef=ef)
         t0 = time.perf_counter()
@@ -63,7 +63,7 @@ def test_config4_hnsw_1m_x_384_recall_against_exact_and_cpu_walk():
         for i in range(0, n_truth, 7):
             assert bs[i].tolist() == [V.hnsw_score(int(D[i][int(x)]), 0) for x in bi[i]]
             assert all(bs[i][j - 1] >= bs[i][j] for j in range(1, k))
-    hn.set_min_beam(32)
+    hn.set_min_beam(0)
     # ---- the CPU HNSW on the same graph ----
     graph = hn.graph(with_rows=True)
     assert graph["n"] == n and graph["m0"] == 32 and graph["m"] == 16 and int(graph["cnt0"].max()) <= 32
@@ -87,8 +87,8 @@ def test_config4_hnsw_1m_x_384_recall_against_exact_and_cpu_walk():
           f"{t_gpu_single * 1e3:.3f} ms/query one at a time")
     assert t_build < 30.0
     assert out["ef128"][0] >= 0.99, out
-    assert out["default_floor32"][0] >= 0.93, out
+    assert out["floor32_optin"][0] >= 0.93, out
     assert out["strict_ef10"][0] >= 0.72, out
-    assert out["default_floor32"][0] >= out["strict_ef10"][0]
+    assert out["floor32_optin"][0] >= out["strict_ef10"][0]
     assert cpu_recall >= 0.98, cpu_recall
     assert abs(cpu_recall - gpu_recall_same) <= 0.03, (cpu_recall, gpu_recall_same)

@@ -592,7 +592,7 @@ class HNSWIndex:
         return g
 
     def set_min_beam(self, min_beam: int) -> None:
-        """Beam floor of searches that name no ef (default 32); 0 = the reference's strict ef = min(k, len)."""
+        """Opt-in beam floor of searches that name no ef; default 0 = the reference's strict ef = min(k, len)."""
         _raise(self._L.vl_index_hnsw_set_min_beam(self._h, int(min_beam)))
 
     def walk_stats(self) -> Tuple[int, int]:

@@ -138,6 +138,7 @@ constexpr uint32_t WALK_LOG_CAP = 8192;          // nodes a walk may mark before
 constexpr uint32_t WALK_SLOTS_MAX = 4096;
 constexpr uint64_t WALK_SCRATCH_BYTES = 2ull << 30;  // ceiling for one scratch's visited sets
 constexpr size_t WALK_POOL_MAX = 16;
+constexpr uint64_t WALK_POOL_BYTES = 8ull << 30;     // ceiling for ALL scratches of one index (idle ones are trimmed to stay under it)
 }  // namespace
 
 WalkScratch::~WalkScratch()
@@ -154,6 +155,10 @@ WalkScratch::~WalkScratch()
 
 // A scratch for up to `walks` walks in flight (fewer slots only mean a query waits for a free wave inside the kernel).
 // Caller holds mu_ (shared or unique), so g_cap_ is stable.
+// The pool is bounded by BYTES of visited sets (WALK_POOL_BYTES), not only by count: when a new scratch would go over
+// the budget the largest idle one is freed first, and when nothing is idle the caller waits for a release.  The device
+// allocation itself runs without pool_mu_ (the slot and its bytes are reserved under the lock), so other searchers keep
+// acquiring and releasing while a scratch is being made.
 WalkScratch* HnswIndex::acquire_scratch(uint64_t walks) const
 {
     const uint32_t words = (uint32_t)((g_cap_ + 31) / 32);
@@ -164,31 +169,71 @@ WalkScratch* HnswIndex::acquire_scratch(uint64_t walks) const
     if (walks > 64) want = 512;
     if (walks > 512) want = max_slots;
     want = std::min<uint64_t>(want, max_slots);
-    std::unique_lock<std::mutex> lk(pool_mu_);
-    for (;;) {
-        WalkScratch* best = nullptr;
-        size_t best_i = 0;
-        for (size_t i = 0; i < pool_free_.size(); ++i) {
-            WalkScratch* c = pool_free_[i];
-            if (c->n_slots >= want && (!best || c->n_slots < best->n_slots)) {
-                best = c;
-                best_i = i;
+    const uint64_t need = want * per_slot;
+    std::vector<std::unique_ptr<WalkScratch>> doomed;  // freed after the lock is dropped (the destructor syncs a stream)
+    {
+        std::unique_lock<std::mutex> lk(pool_mu_);
+        for (;;) {
+            WalkScratch* best = nullptr;
+            size_t best_i = 0;
+            for (size_t i = 0; i < pool_free_.size(); ++i) {
+                WalkScratch* c = pool_free_[i];
+                if (c->n_slots >= want && (!best || c->n_slots < best->n_slots)) {
+                    best = c;
+                    best_i = i;
+                }
             }
+            const size_t made = pool_all_.size() + pool_pending_;
+            const bool room = made < WALK_POOL_MAX && (pool_bytes_ + need <= WALK_POOL_BYTES || made == 0);
+            if (!best && !room && !pool_free_.empty()) {
+                // over the count or the byte budget: a smaller idle scratch serves (the kernel queues walks on its
+                // slots) unless freeing idle ones makes room for the size asked for
+                uint64_t idle = 0;
+                for (WalkScratch* c : pool_free_) idle += (uint64_t)c->n_slots * (c->words + c->log_cap) * sizeof(uint32_t);
+                if (pool_all_.size() + pool_pending_ <= WALK_POOL_MAX && pool_bytes_ - idle + need <= WALK_POOL_BYTES) {
+                    while (!pool_free_.empty() && (pool_bytes_ + need > WALK_POOL_BYTES || pool_all_.size() + pool_pending_ >= WALK_POOL_MAX)) {
+                        size_t big = 0;
+                        for (size_t i = 1; i < pool_free_.size(); ++i)
+                            if (pool_free_[i]->n_slots > pool_free_[big]->n_slots) big = i;
+                        WalkScratch* v = pool_free_[big];
+                        pool_free_.erase(pool_free_.begin() + (long)big);
+                        pool_bytes_ -= (uint64_t)v->n_slots * (v->words + v->log_cap) * sizeof(uint32_t);
+                        for (size_t i = 0; i < pool_all_.size(); ++i)
+                            if (pool_all_[i].get() == v) {
+                                doomed.push_back(std::move(pool_all_[i]));
+                                pool_all_.erase(pool_all_.begin() + (long)i);
+                                break;
+                            }
+                    }
+                    continue;  // re-evaluate: there is room now
+                }
+                best = pool_free_.back();
+                best_i = pool_free_.size() - 1;
+            }
+            if (best) {
+                pool_free_.erase(pool_free_.begin() + (long)best_i);
+                lk.unlock();
+                doomed.clear();
+                return best;
+            }
+            if (room) break;
+            pool_cv_.wait(lk);
         }
-        if (!best && pool_all_.size() >= WALK_POOL_MAX && !pool_free_.empty()) {  // pool full: any free one does
-            best = pool_free_.back();
-            best_i = pool_free_.size() - 1;
-        }
-        if (best) {
-            pool_free_.erase(pool_free_.begin() + (long)best_i);
-            return best;
-        }
-        if (pool_all_.size() < WALK_POOL_MAX) break;
-        pool_cv_.wait(lk);
+        pool_pending_ += 1;  // the slot and its bytes are reserved; the allocation runs unlocked
+        pool_bytes_ += need;
     }
-    // make a new one (outside nobody else can take its place: the count is reserved by pushing it first)
+    doomed.clear();
+    auto unreserve = [&]() {
+        {
+            std::lock_guard<std::mutex> lk(pool_mu_);
+            pool_pending_ -= 1;
+            pool_bytes_ -= need;
+        }
+        pool_cv_.notify_all();
+    };
     std::unique_ptr<WalkScratch> ws(new (std::nothrow) WalkScratch());
     if (!ws) {
+        unreserve();
         set_last_error("host allocation failed");
         return nullptr;
     }
@@ -204,11 +249,16 @@ WalkScratch* HnswIndex::acquire_scratch(uint64_t walks) const
     if (e == hipSuccess) e = hipStreamSynchronize(ws->stream);
     if (e != hipSuccess) {
         (void)hipGetLastError();
+        unreserve();
         set_last_error(std::string("walk scratch allocation failed: ") + hipGetErrorString(e));
         return nullptr;  // ~WalkScratch frees what was made
     }
     WalkScratch* raw = ws.get();
-    pool_all_.push_back(std::move(ws));
+    {
+        std::lock_guard<std::mutex> lk(pool_mu_);
+        pool_pending_ -= 1;
+        pool_all_.push_back(std::move(ws));
+    }
     return raw;
 }
 
@@ -227,6 +277,7 @@ void HnswIndex::drop_scratch_pool()
     std::lock_guard<std::mutex> lk(pool_mu_);
     pool_free_.clear();
     pool_all_.clear();  // bitmaps are sized by the graph's capacity: rebuilt on demand
+    pool_bytes_ = 0;
 }
 
 HnswGraphView HnswIndex::view(const WalkScratch* ws) const
@@ -692,10 +743,10 @@ int HnswIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_len, 
     if (max_candidates == 0) return OK;
     if (!queries || !out_ids || !out_scores) return ERR_INVALID_ARG;
     // hnsw.nearest(&q, ef = max_candidates, ..) (:454); an explicit ef widens the beam, never narrows it
-    // ef == 0 (the trait's search): the reference hands ef = min(k, len) to the crate's walk; this walk keeps a beam of
-    // at least min_beam_ entries (default 32) and returns the best min(k, len) of it -- never fewer results, and on
-    // embedding-like data recall@10 0.96 instead of 0.78 at N = 1 M for about the same batch throughput.
-    // vl_index_hnsw_set_min_beam(h, 0) is the strict ef = min(k, len).
+    // ef == 0 (the trait's search): the reference hands ef = min(k, len) to the crate's walk, and so does this one by
+    // default (min_beam_ = 0).  A caller that opted in (vl_index_hnsw_set_min_beam) keeps a beam of at least min_beam_
+    // entries and gets the best min(k, len) of it -- never fewer results; with a floor of 32 on embedding-like data
+    // recall@10 is 0.96 instead of 0.78 at N = 1 M for about the same batch throughput.
     uint64_t ef_walk = ef ? std::max<uint64_t>(max_candidates, ef) : std::max<uint64_t>(max_candidates, min_beam_.load());
     if (ef_walk > (uint64_t)HNSW_MAX_EF) {
         if (max_candidates > (uint64_t)HNSW_MAX_EF) {

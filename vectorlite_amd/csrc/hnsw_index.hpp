@@ -117,6 +117,8 @@ private:
     mutable std::condition_variable pool_cv_;
     mutable std::vector<std::unique_ptr<WalkScratch>> pool_all_;
     mutable std::vector<WalkScratch*> pool_free_;
+    mutable size_t pool_pending_ = 0;    // scratches being allocated (slot and bytes already counted)
+    mutable uint64_t pool_bytes_ = 0;    // visited-set bytes of pool_all_ + pending
 
     // device graph
     uint32_t* d_nbr0_ = nullptr;
@@ -143,7 +145,7 @@ private:
     std::vector<uint8_t> live_;
     uint64_t live_count_ = 0;
 
-    std::atomic<uint32_t> min_beam_{32};
+    std::atomic<uint32_t> min_beam_{0};  // 0 = the reference's strict ef = min(k, len); a wider floor is opt-in
     mutable std::atomic<uint64_t> stat_queries_{0}, stat_evals_{0};  // stat_evals_: the exact-fallback's share only
     mutable Coalescer<CoalesceReq> co_;
 

@@ -1343,58 +1343,10 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
     if (nq == 0 || n_rows == 0 || n_rows >= 0xFFFFFFFFull) return hipErrorInvalidValue;
     if (!mfma_scan_supported(dim, metric) || nq > w.nq_cap) return hipErrorInvalidValue;
     const uint32_t ldb = mfma_ldb(dim);
-    // launch shape: (waves per workgroup, 32-query tiles per wave); 256 queries per workgroup
-    const int shape = env_shape(ldb);  // 81 = 8 waves x 1 tile, 42 = 4 waves x 2 tiles, 41 = 4 waves x 1 tile, 82 = 8 waves, K split over pairs
-    const int nwaves = shape / 10, qt = shape == 82 ? 1 : shape % 10;
-    const uint32_t qpb = (uint32_t)(shape == 82 ? nwaves / 2 : nwaves) * 32 * (uint32_t)qt;
-    const uint32_t nq_pad = (nq + qpb - 1) / qpb * qpb;
-    if (nq_pad > w.nq_pad_cap) return hipErrorInvalidValue;
-    // the 8-wave shape works on 64-row tiles (two 32-row MFMA blocks per barrier), the others on 32-row tiles
-    // (up to d = 384; at 512 the eight 16-byte pieces per thread of a 64-row tile spill)
-    const uint32_t tile_rows = (shape == 81 && ldb <= 384) ? 2u * MF_ROWS : (uint32_t)MF_ROWS;
-    const uint32_t n_tiles = (uint32_t)((n_rows + tile_rows - 1) / tile_rows);
     __bf16* q16 = reinterpret_cast<__bf16*>(w.q_bf16);
     const __bf16* slab = reinterpret_cast<const __bf16*>(slab_bf16);
-    {
-        const size_t total = (size_t)nq_pad * ldb;
-        const int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
-        hipLaunchKernelGGL(k_queries_bf16, dim3(grid), dim3(256), 0, s, q64, nq, nq_pad, dim, ldb, q16);
-    }
-    hipError_t e = hipMemsetAsync(w.cnt, 0, (size_t)nq_pad * sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
-
-    // pass 0: a sample of the tiles, one contiguous range per workgroup = one "group" per workgroup
-    // The threshold is exceeded by about 64 rows of the sample, i.e. by a fraction 64 / sample_rows of all
-    // rows: a wave then appends 32 queries x 512 rows x that fraction candidates per trip to its 128-entry
-    // ring segment.  A sample of at least 65536 rows (or the whole index) keeps that near 16; with only
-    // 8192 sampled rows an index of 10^5 rows overflowed the rings and every query fell back.
-    uint32_t sample_tiles = n_tiles / 16;
-    const uint32_t min_tiles = 65536u / tile_rows;
-    const uint32_t min_sample = n_tiles < min_tiles ? n_tiles : min_tiles;
-    if (sample_tiles < min_sample) sample_tiles = min_sample;
-    const uint32_t n_groups = sample_tiles < (uint32_t)MFMA_GROUPS ? sample_tiles : (uint32_t)MFMA_GROUPS;
-    const dim3 grid0(n_groups, nq_pad / qpb);
-    const uint64_t sample_rows = std::min<uint64_t>((uint64_t)sample_tiles * tile_rows, n_rows);
-    // all query chunks of a launch are co-resident (one workgroup per CU) and walk the same tile
-    // sequence, so a tile is fetched from HBM once and served to the other chunks by L2 / Infinity Cache
-    const uint32_t n_chunks = nq_pad / qpb;
-    const int pass1_blocks = (int)std::min<uint32_t>(n_tiles, (uint32_t)env_grid(n_chunks));
-    // Pass 1 runs in stages of growing size (3/16, 4/16, 9/16 of the tiles); between stages the thresholds
-    // are tightened from the candidates found so far (k_refine_thresholds).  Short scans keep one stage.
-    uint32_t stage_end[4] = {0, n_tiles, n_tiles, n_tiles};
-    int n_stages = 1;
-    {
-        const char* se = getenv("VL_MFMA_STAGES");
-        const int want = se && *se ? atoi(se) : 3;
-        if (want >= 2 && n_tiles >= 64u * (uint32_t)pass1_blocks) {
-            n_stages = want >= 3 ? 3 : 2;
-            stage_end[1] = (uint32_t)((uint64_t)n_tiles * 3 / 16);
-            stage_end[2] = n_stages == 3 ? (uint32_t)((uint64_t)n_tiles * 7 / 16) : n_tiles;
-            stage_end[3] = n_tiles;
-        }
-    }
-
-    // ---- row-stationary kernel (k_mfma_rows): every dimension up to 384; VL_MFMA_KERNEL=tile keeps the LDS-tile kernel ----
+    // ---- row-stationary kernel (k_mfma_rows): every stride the index pads to (128 / 256 / 384 / 512 / 768);
+    //      VL_MFMA_KERNEL=tile keeps the LDS-tile kernel.  Each path stages its own queries and clears cnt once. ----
     {
         if (mfma_rows_kernel(dim)) {  // slab_bf16 is then the fragment-major slab (launch_rows_bf16_frag)
             const uint32_t rq = (uint32_t)rs_qpb(ldb);
@@ -1458,6 +1410,56 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
             if (!r_launched) return hipErrorInvalidValue;
             hipLaunchKernelGGL(k_select_candidates, dim3((nq + 3) / 4), dim3(256), 0, s, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, nq, out_lists);
             return hipGetLastError();
+        }
+    }
+
+    // ---- LDS-tile kernel (k_mfma_scan) ----
+    // launch shape: (waves per workgroup, 32-query tiles per wave); 256 queries per workgroup
+    const int shape = env_shape(ldb);  // 81 = 8 waves x 1 tile, 42 = 4 waves x 2 tiles, 41 = 4 waves x 1 tile, 82 = 8 waves, K split over pairs
+    const int nwaves = shape / 10, qt = shape == 82 ? 1 : shape % 10;
+    const uint32_t qpb = (uint32_t)(shape == 82 ? nwaves / 2 : nwaves) * 32 * (uint32_t)qt;
+    const uint32_t nq_pad = (nq + qpb - 1) / qpb * qpb;
+    if (nq_pad > w.nq_pad_cap) return hipErrorInvalidValue;
+    // the 8-wave shape works on 64-row tiles (two 32-row MFMA blocks per barrier), the others on 32-row tiles
+    // (up to d = 384; at 512 the eight 16-byte pieces per thread of a 64-row tile spill)
+    const uint32_t tile_rows = (shape == 81 && ldb <= 384) ? 2u * MF_ROWS : (uint32_t)MF_ROWS;
+    const uint32_t n_tiles = (uint32_t)((n_rows + tile_rows - 1) / tile_rows);
+    {
+        const size_t total = (size_t)nq_pad * ldb;
+        const int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_queries_bf16, dim3(grid), dim3(256), 0, s, q64, nq, nq_pad, dim, ldb, q16);
+    }
+    hipError_t e = hipMemsetAsync(w.cnt, 0, (size_t)nq_pad * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+
+    // pass 0: a sample of the tiles, one contiguous range per workgroup = one "group" per workgroup
+    // The threshold is exceeded by about 64 rows of the sample, i.e. by a fraction 64 / sample_rows of all
+    // rows: a wave then appends 32 queries x 512 rows x that fraction candidates per trip to its 128-entry
+    // ring segment.  A sample of at least 65536 rows (or the whole index) keeps that near 16; with only
+    // 8192 sampled rows an index of 10^5 rows overflowed the rings and every query fell back.
+    uint32_t sample_tiles = n_tiles / 16;
+    const uint32_t min_tiles = 65536u / tile_rows;
+    const uint32_t min_sample = n_tiles < min_tiles ? n_tiles : min_tiles;
+    if (sample_tiles < min_sample) sample_tiles = min_sample;
+    const uint32_t n_groups = sample_tiles < (uint32_t)MFMA_GROUPS ? sample_tiles : (uint32_t)MFMA_GROUPS;
+    const dim3 grid0(n_groups, nq_pad / qpb);
+    const uint64_t sample_rows = std::min<uint64_t>((uint64_t)sample_tiles * tile_rows, n_rows);
+    // all query chunks of a launch are co-resident (one workgroup per CU) and walk the same tile
+    // sequence, so a tile is fetched from HBM once and served to the other chunks by L2 / Infinity Cache
+    const uint32_t n_chunks = nq_pad / qpb;
+    const int pass1_blocks = (int)std::min<uint32_t>(n_tiles, (uint32_t)env_grid(n_chunks));
+    // Pass 1 runs in stages of growing size (3/16, 4/16, 9/16 of the tiles); between stages the thresholds
+    // are tightened from the candidates found so far (k_refine_thresholds).  Short scans keep one stage.
+    uint32_t stage_end[4] = {0, n_tiles, n_tiles, n_tiles};
+    int n_stages = 1;
+    {
+        const char* se = getenv("VL_MFMA_STAGES");
+        const int want = se && *se ? atoi(se) : 3;
+        if (want >= 2 && n_tiles >= 64u * (uint32_t)pass1_blocks) {
+            n_stages = want >= 3 ? 3 : 2;
+            stage_end[1] = (uint32_t)((uint64_t)n_tiles * 3 / 16);
+            stage_end[2] = n_stages == 3 ? (uint32_t)((uint64_t)n_tiles * 7 / 16) : n_tiles;
+            stage_end[3] = n_tiles;
         }
     }
 
