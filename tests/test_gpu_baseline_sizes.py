@@ -155,6 +155,22 @@ def test_headline_10m_x_384_fast_equals_exact_and_batch_equals_single(V):
     for qi in list(range(0, 300, 23)) + [255, 256, 299]:
         si, ss = idx.search_arrays(Q[qi], k, 0)
         assert bi[qi].tolist() == si.tolist() and bs[qi].tolist() == ss.tolist(), qi
+    # C5's FULL product: 4096 queries x 10 M rows, cosine -- two launch sequences of 2048 queries on the MFMA filter;
+    # 64 sampled rows (both sequences, their first / last queries and the chunk edges) against single searches
+    Q5 = unit_rows(np.random.default_rng(5555), 4096, dim)
+    idx.search_batch(Q5[:256], k, 0)
+    idx.profile_read()
+    idx.profile_enable(True)
+    bi5, bs5, bn5 = idx.search_batch(Q5, k, 0)
+    idx.profile_enable(False)
+    passes5 = idx.profile_read()[0]
+    assert passes5 <= 2 + 8, passes5          # two sequences (+ a few queries redone one by one at most)
+    assert bn5.tolist() == [k] * 4096
+    sample = sorted(set([0, 1, 127, 128, 2047, 2048, 2049, 2175, 2176, 4094, 4095] + list(range(13, 4096, 77))))[:64]
+    assert any(q < 2048 for q in sample) and any(q >= 2048 for q in sample)
+    for qi in sample:
+        si, ss = idx.search_arrays(Q5[qi], k, 0)
+        assert bi5[qi].tolist() == si.tolist() and bs5[qi].tolist() == ss.tolist(), qi
     # a stored row finds itself first with score 1 (to rounding), its id is the bijection of its position
     probe = 7_654_321
     v = idx.get_vector(int(ids_for(probe, 1)[0])).values

@@ -220,6 +220,43 @@ def test_walk_stats_count_distance_evaluations(V):
     assert q2 == 51 and e2 > e
 
 
+def test_default_walk_is_the_reference_strict_beam(V):
+    """The trait's search() names no ef: the reference walks with ef = min(k, len) (src/index/hnsw.rs:437,454) and so
+    does this handle by default.  Walks are deterministic, so the distance evaluations of the default search must be
+    EXACTLY those of an explicit ef = min(k, len) walk, and fewer than those of the opt-in beam floor of 32."""
+    rng = np.random.default_rng(11)
+    n, dim, k = 5000, 24, 10
+    z = rng.standard_normal((n, dim))
+    idx = V.HNSWIndex(dim, V.SimilarityMetric.Euclidean)
+    idx.add_rows(np.arange(n, dtype=np.uint64), z)
+    Q = z[:40] + 0.01
+
+    def evals(fn):
+        q0, e0 = idx.walk_stats()
+        out = fn()
+        q1, e1 = idx.walk_stats()
+        assert q1 - q0 == len(Q)
+        return e1 - e0, out
+
+    e_default, r_default = evals(lambda: idx.search_batch(Q, k, V.SimilarityMetric.Euclidean))
+    e_ef10, r_ef10 = evals(lambda: idx.search_batch(Q, k, V.SimilarityMetric.Euclidean, ef=k))
+    e_ef32, r_ef32 = evals(lambda: idx.search_batch(Q, k, V.SimilarityMetric.Euclidean, ef=32))
+    assert e_default == e_ef10 and e_default < e_ef32, (e_default, e_ef10, e_ef32)
+    assert r_default[0].tolist() == r_ef10[0].tolist() and r_default[1].tolist() == r_ef10[1].tolist()
+    idx.set_min_beam(32)                       # opt-in deviation: the work of an ef = 32 walk, still min(k, len) results
+    e_floor, r_floor = evals(lambda: idx.search_batch(Q, k, V.SimilarityMetric.Euclidean))
+    assert e_floor == e_ef32 and r_floor[2].tolist() == [k] * len(Q)
+    assert r_floor[0].tolist() == r_ef32[0].tolist()
+    idx.set_min_beam(0)
+    e_again, _ = evals(lambda: idx.search_batch(Q, k, V.SimilarityMetric.Euclidean))
+    assert e_again == e_default
+    # k > len on a tiny index: ef = len
+    tiny = V.HNSWIndex(dim, V.SimilarityMetric.Euclidean)
+    tiny.add_rows(np.arange(6, dtype=np.uint64), z[:6])
+    gi, gs = tiny.search_arrays(z[0], 50, V.SimilarityMetric.Euclidean)
+    assert len(gi) == 6 and gi[0] == 0
+
+
 def test_coalesced_concurrent_hnsw_searches_match_lone_searches(V):
     """vl_index_set_coalescing on an HNSW handle: concurrent search() calls share walk launches and each
     caller still gets exactly its lone-search result and status (walks are deterministic)."""

@@ -6,5 +6,5 @@ TAG=$1; shift
 cd "$(dirname "$0")/.."
 O=vectorlite_amd/csrc/_obj
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Iinclude "$@" -c vectorlite_amd/csrc/mfma_scan.hip -o /tmp/mfma_scan_$TAG.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o vectorlite_amd/libvl_$TAG.so $O/kernels.o $O/hnsw.o /tmp/mfma_scan_$TAG.o $O/shard.o $O/flat_index.o $O/hnsw_index.o $O/shard_comm.o $O/vlc_loader.o $O/c_api.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o vectorlite_amd/libvl_$TAG.so $(ls $O/*.o | grep -v "/mfma_scan.o$") /tmp/mfma_scan_$TAG.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 echo built vectorlite_amd/libvl_$TAG.so

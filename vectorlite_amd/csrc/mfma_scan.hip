@@ -635,7 +635,11 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     // blk * 32 rows + rb * 16 rows + s KB + 16 lane.  (With row-major rows every fragment load touched 16 half
     // lines; at 128 queries per workgroup the L2 request rate, not the matrix pipe, then set the pace.)
     const uint32_t lane_off = (uint32_t)lane * 16u;
+#ifdef RS_DBG_HOTLOAD  // diagnostic: every load hits L2 (the waves re-read the same RS_DBG_HOTLOAD blocks): what do the MISSES cost?
+    auto a_ptr = [&](uint32_t blk) { return reinterpret_cast<const unsigned char*>(slab16) + (size_t)(blk % (uint32_t)(RS_DBG_HOTLOAD)) * (32 * ROW_BYTES) + lane_off; };
+#else
     auto a_ptr = [&](uint32_t blk) { return reinterpret_cast<const unsigned char*>(slab16) + (size_t)blk * (32 * ROW_BYTES) + lane_off; };
+#endif
     bf16x8 afrag[2][KSP];
     f32x4 aux[2] = {f32x4{1.f, 1.f, 1.f, 1.f}, f32x4{1.f, 1.f, 1.f, 1.f}};
     f32x4 aux2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
