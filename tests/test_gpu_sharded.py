@@ -211,3 +211,31 @@ def test_a_nan_score_on_one_shard_is_the_whole_calls_panic():
         assert n.tolist() == [5, 5]
     finally:
         comm.close()
+
+
+def test_a_rank_that_cannot_size_its_exchange_buffers_fails_the_call_on_every_rank_and_the_comm_survives():
+    """Advisor round 2: a rank-local failure before the big all-gather must not leave the peers waiting in it.  Buffer growth
+    is decided by (nq, ks, world) alone, so all ranks take a pre-flight status all-gather together; a rank whose allocation
+    fails (injected here) says so there, every rank returns VL_ERR_OOM, and the communicator stays usable."""
+    import vectorlite_amd as V
+    from vectorlite_amd.sharded import Comm, ShardedFlatIndex
+    rng = np.random.default_rng(12)
+    rows = rng.standard_normal((4000, 32))
+    shard = V.FlatIndex(32, device=0)
+    shard.add_rows(np.arange(4000, dtype=np.uint64), rows, validate=False)
+    Q = rng.standard_normal((9, 32))
+    comm = Comm(Comm.unique_id(), 1, 0, 0)
+    try:
+        sh = ShardedFlatIndex(shard, comm=comm)
+        os.environ["VL_SHARD_INJECT_OOM"] = "0"
+        try:
+            with pytest.raises(V.VectorLiteError) as ei:
+                sh.search_batch(Q, 10, V.SimilarityMetric.Cosine)
+            assert "could not size its exchange buffers" in str(ei.value), str(ei.value)
+        finally:
+            del os.environ["VL_SHARD_INJECT_OOM"]
+        i, s, n = sh.search_batch(Q, 10, V.SimilarityMetric.Cosine)      # the communicator was not aborted
+        bi, bs, bn = shard.search_batch(Q, 10, V.SimilarityMetric.Cosine)
+        assert i.tolist() == bi.tolist() and s.tolist() == bs.tolist() and n.tolist() == bn.tolist()
+    finally:
+        comm.close()

@@ -11,7 +11,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 O.build()
 t_end = time.time() + budget
-cases = checks = 0
+cases = checks = n_multi = 0
 paths = {}
 case_seed = seed0
 t_report = time.time() + 30
@@ -39,7 +39,15 @@ while time.time() < t_end:
     else:
         c = rng.standard_normal((8, dim)); rows = c[rng.integers(0, 8, size=n)] + 1e-4 * rng.standard_normal((n, dim))
     ids = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(11)) % np.uint64(2 ** 50)
-    gpu = V.FlatIndex(dim); gpu.add_rows(ids, rows, validate=False)
+    multi = None
+    if rng.random() < 0.25:  # one handle over several parts (vl_flat_create_multi; the parts share the one card here)
+        multi = (["replicas", "row_shards"][int(rng.integers(0, 2))], [0] * int(rng.integers(2, 4)))
+        gpu = V.MultiFlatIndex(dim, multi[1], multi[0])
+        cut = int(rng.integers(0, n + 1))  # two bulk pieces: the shards level out, insertion order stays global
+        gpu.add_rows(ids[:cut], rows[:cut], validate=False); gpu.add_rows(ids[cut:], rows[cut:], validate=False)
+        n_multi += 1
+    else:
+        gpu = V.FlatIndex(dim); gpu.add_rows(ids, rows, validate=False)
     ref = O.FlatOracle(dim, ids, rows)
     nq = int(rng.choice([1, 2, 5, 9, 33]))
     if n >= 9000 and dim <= 128 and rng.random() < 0.5:
@@ -53,10 +61,12 @@ while time.time() < t_end:
     m = int(rng.integers(0, 4))
     k = int(rng.choice([1, 10, 48, 60, 61, 100, 220, 221, 500]))
     mode = "batch" if nq >= 64 else rng.choice(["single", "batch", "bf16", "positions"])
+    if multi is not None and mode in ("bf16", "positions"):
+        mode = "single"
     if mode == "bf16":
         gpu.set_single_filter("bf16")
     if mode == "batch":
-        if rng.integers(0, 2):  # half of the batches come from device memory (vl_index_search_batch_dev)
+        if multi is None and rng.integers(0, 2):  # half of the batches come from device memory (vl_index_search_batch_dev)
             import torch
             bi, bs, bn = gpu.search_batch_device(torch.from_numpy(np.ascontiguousarray(Q)).to('cuda:0'), k, m)
         else:
@@ -74,10 +84,10 @@ while time.time() < t_end:
     for i in range(nq):
         ri, rs = ref.search(Q[i], k, m)
         if got[i][0].tolist() != ri.tolist() or got[i][1].tolist() != rs.tolist():
-            print(f"MISMATCH seed {case_seed}: dim {dim} n {n} kind {kind} metric {m} k {k} mode {mode} query {i}", flush=True)
+            print(f"MISMATCH seed {case_seed}: dim {dim} n {n} kind {kind} metric {m} k {k} mode {mode} multi {multi} query {i}", flush=True)
             print(" got ", got[i][0][:8].tolist(), got[i][1][:4].tolist()); print(" want", ri[:8].tolist(), rs[:4].tolist())
             sys.exit(1)
         checks += 1
     cases += 1
     del gpu, ref
-print(f"fuzz campaign: {cases} cases, {checks} query checks in {budget:.0f}s from seed {seed0}: all bit-identical; single-query paths seen {paths}")
+print(f"fuzz campaign: {cases} cases, {checks} query checks in {budget:.0f}s from seed {seed0}: all bit-identical; {n_multi} cases on multi-part handles (replicas / row shards over 2-3 parts); single-query paths seen {paths}")
