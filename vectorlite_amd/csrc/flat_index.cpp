@@ -87,13 +87,9 @@ Workspace::~Workspace()
     void* host[] = {h_q64, h_result, h_nan, mf_h_q64, mf_h_result, mf_h_dom};
     for (void* p : host)
         if (p) (void)hipHostFree(p);
-    if (mf.side) (void)hipStreamSynchronize(mf.side);  // a live refiner still looking at the buffers below
-    void* mfd[] = {mf.q_bf16, mf.gmax, mf.thr, mf.cand, mf.cnt, mf.live_done, mf_d_q64, mf_lists};
+    void* mfd[] = {mf.q_bf16, mf.gmax, mf.thr, mf.cand, mf.cnt, mf_d_q64, mf_lists};
     for (void* p : mfd)
         if (p) (void)hipFree(p);
-    if (mf.ev_fork) (void)hipEventDestroy(mf.ev_fork);
-    if (mf.ev_join) (void)hipEventDestroy(mf.ev_join);
-    if (mf.side) (void)hipStreamDestroy(mf.side);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (stream) (void)hipStreamDestroy(stream);
@@ -1174,11 +1170,7 @@ int GpuFlatIndex::ensure_mfma_scratch(Workspace* ws) const
     const size_t nqp = nqc + 256;  // whole query chunks (128 / 96 / 256 queries) past the last query
     VL_HIP(hipMalloc(&ws->mf.q_bf16, nqp * ldb * 2));
     VL_TRY(dev_alloc(&ws->mf.gmax, nqc * MFMA_GROUPS));
-    VL_TRY(dev_alloc(&ws->mf.thr, nqp));
-    VL_TRY(dev_alloc(&ws->mf.live_done, 1));
-    VL_HIP(hipStreamCreateWithFlags(&ws->mf.side, hipStreamNonBlocking));
-    VL_HIP(hipEventCreateWithFlags(&ws->mf.ev_fork, hipEventDisableTiming));
-    VL_HIP(hipEventCreateWithFlags(&ws->mf.ev_join, hipEventDisableTiming));
+    VL_TRY(dev_alloc(&ws->mf.thr, nqc));
     VL_TRY(dev_alloc(&ws->mf.cand, nqc * MFMA_CAND_CAP));
     VL_TRY(dev_alloc(&ws->mf.cnt, nqp));
     VL_TRY(dev_alloc(&ws->mf_d_q64, nqc * (dim_ + 1)));

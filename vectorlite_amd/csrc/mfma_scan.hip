@@ -531,8 +531,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
                                                               uint32_t blk_begin, uint32_t blk_end, uint32_t n_rows,
                                                               int* __restrict__ gmax, uint32_t n_groups, uint32_t gpw,
                                                               const float* __restrict__ thr, Cand32* __restrict__ cand,
-                                                              uint32_t* __restrict__ cnt, uint32_t cap, uint32_t live,
-                                                              uint32_t* __restrict__ live_done)
+                                                              uint32_t* __restrict__ cnt, uint32_t cap)
 {
     constexpr int LDB = KSTEPS * 16;
     constexpr int ROW_BYTES = LDB * 2;
@@ -686,12 +685,10 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
             const uint32_t qq = chunk_base + ring_q[idx];
             const uint32_t slot = atomicAdd(&cnt[qq], 1u);
             if (slot < cap) {
-                // ONE 8-byte agent-scope store: the live refiner (k_refine_live, other CUs, maybe another XCD) sees an
-                // entry whole or not at all (the buffer's head is pre-set to "unwritten")
-                const unsigned long long packed =
-                    ((unsigned long long)ring_pos[idx] << 32) | (unsigned long long)__float_as_uint(ring_key[idx]);
-                __hip_atomic_store(reinterpret_cast<unsigned long long*>(cand + (size_t)qq * cap + slot), packed, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+                Cand32 c;
+                c.key = ring_key[idx];
+                c.pos = ring_pos[idx];
+                cand[(size_t)qq * cap + slot] = c;
             }
         }
         if (my_cnt > (uint32_t)RS_SEG) {  // the segment overflowed: candidates of any of the workgroup's queries may be lost -> host redoes them
@@ -707,19 +704,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
 #ifdef RS_PRIO
     if (wave >= RS_NWAVES / 2) __builtin_amdgcn_s_setprio(1);
 #endif
-    // live mode: thr[] is raised WHILE this launch runs (k_refine_live on the CUs this grid leaves idle: the 64th best
-    // candidate found so far by all workgroups); every LIVE_EVERY-th block the wave re-reads its queries' thresholds
-    // (agent-scope loads: L2-served, never from this CU's L1).  thr[] is padded with +inf up to the chunk end, so the
-    // loads need no mask; a stale value is an older, lower threshold -- still a valid bound.
-    constexpr uint32_t LIVE_EVERY = 4;
-    uint32_t live_it = 0;
-    const uint32_t* thr_u = reinterpret_cast<const uint32_t*>(thr) + chunk_base + c16;
     for (; b < blk_end; b += stride) {
-        if (MODE == 1 && live && (live_it++ % LIVE_EVERY) == LIVE_EVERY - 1) {  // wave-uniform
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
-                thr_q[qb] = __uint_as_float(__hip_atomic_load(thr_u + qb * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        }
         const uint32_t nb_raw = b + stride;
         const uint32_t nb = nb_raw < blk_end ? nb_raw : b_last;  // the tail re-reads a valid block; its values are never used
         const unsigned char* pn = a_ptr(nb);
@@ -908,7 +893,6 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
 #endif
     if (MODE == 1) {
         if (my_cnt) flush_wave();
-        if (live && lane == 0) __hip_atomic_fetch_add(live_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         // group maximum = max over every wave of the workgroup (its rows are held by no other group)
 #pragma unroll
@@ -1018,15 +1002,11 @@ __global__ __launch_bounds__(256) void k_scan_bf16(const u32x4* __restrict__ sla
 // row: every row would be a candidate and its wave's ring segment would overflow, taking the workgroup's other 255
 // queries down with it.  It gets T_q = +inf -- no candidates at all; the host answers it on the exact path anyway.
 __global__ __launch_bounds__(256) void k_thresholds(const int* __restrict__ gmax, uint32_t n_groups, uint32_t nq,
-                                                    const double* __restrict__ q_norms, float* __restrict__ thr,
-                                                    uint32_t nq_pad = 0)
+                                                    const double* __restrict__ q_norms, float* __restrict__ thr)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= nq) {
-        if (q < nq_pad && lane == 0) thr[q] = INFINITY;  // padding queries of the last chunk never pass (live mode reads them unmasked)
-        return;
-    }
+    if (q >= nq) return;
     constexpr int VALS = MFMA_GROUPS / 64;  // all loads first, then one selection: no load -> insert -> load chain
     float v[VALS];
 #pragma unroll
@@ -1156,60 +1136,6 @@ __global__ __launch_bounds__(256) void k_refine_thresholds(const Cand32* __restr
     }
     const float t64 = read_lane(L.key, 63);
     if (lane == 0 && t64 > thr[q]) thr[q] = t64;
-}
-
-// Live refinement: k_refine_thresholds as a loop that runs BESIDE a pass-1 launch, on the CUs its grid leaves idle
-// (config 3's shard: 23 x 11 = 253 workgroups on 256 CUs).  Every wave walks the queries round-robin: the entries of the
-// buffer's head (the first LIVE_LOOK slots, pre-set to "unwritten" = all ones; the scan stores an entry with one 8-byte
-// agent-scope store) that are written are >= 64 distinct rows of the index as soon as 64 of them are, so their 64th
-// best key is a valid lower bound of the query's 64th best key whatever else is in flight; it is published with an
-// agent-scope store when it raises the threshold.  Thresholds then follow 64 / (rows scanned so far) continuously instead
-// of stage by stage: a third of the candidates, no relaunch.
-// The loop ends when every scanning wave has reported (live_done == expect) -- or after max_ticks of the 100 MHz
-// realtime counter (a bound every wave reaches even if the scan never starts).
-constexpr uint32_t LIVE_LOOK = 512;
-__global__ __launch_bounds__(256) void k_refine_live(const Cand32* __restrict__ cand, const uint32_t* __restrict__ cnt,
-                                                     uint32_t cap, uint32_t nq, float* __restrict__ thr,
-                                                     const uint32_t* __restrict__ live_done, uint32_t expect,
-                                                     unsigned long long max_ticks)
-{
-    const int lane = threadIdx.x & 63;
-    const uint32_t wid = blockIdx.x * 4 + (threadIdx.x >> 6), n_w = gridDim.x * 4;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    for (uint32_t sweep = 0; sweep < 100000u; ++sweep) {
-        for (uint32_t q = wid; q < nq; q += n_w) {
-            const uint32_t done = __hip_atomic_load(live_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (done >= expect || __builtin_amdgcn_s_memrealtime() - t0 > max_ticks) return;  // wave-uniform
-            const uint32_t n = __hip_atomic_load(cnt + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (n < 64u || n > cap) continue;
-            const uint32_t look = n < LIVE_LOOK ? n : LIVE_LOOK;
-            float v[LIVE_LOOK / 64];
-            uint32_t n_ok = 0;
-#pragma unroll
-            for (int i = 0; i < (int)(LIVE_LOOK / 64); ++i) {
-                const uint32_t j = (uint32_t)(lane + 64 * i);
-                unsigned long long e = ~0ull;
-                if (j < look)
-                    e = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(cand + (size_t)q * cap + j), __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_AGENT);
-                const bool ok = (uint32_t)(e >> 32) != 0xFFFFFFFFu;  // position all ones = not written yet
-                v[i] = ok ? __uint_as_float((uint32_t)e) : -INFINITY;
-                n_ok += (uint32_t)__popcll(__ballot(ok));
-            }
-            if (n_ok < 64u) continue;  // wave-uniform
-            const float t64 = kth64_of_wave<LIVE_LOOK / 64>(v);
-            if (lane == 0) {
-                const float cur = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(thr + q), __ATOMIC_RELAXED,
-                                                                    __HIP_MEMORY_SCOPE_AGENT));
-                if (t64 > cur)
-                    __hip_atomic_store(reinterpret_cast<uint32_t*>(thr + q), __float_as_uint(t64), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        __builtin_amdgcn_s_sleep(32);
-        const uint32_t done = __hip_atomic_load(live_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (done >= expect || __builtin_amdgcn_s_memrealtime() - t0 > max_ticks) return;
-    }
 }
 
 // f64 queries -> bf16 [nq_pad, ldb] (zero padded rows and columns), rounded f64 -> f32 -> bf16 (RNE).
@@ -1436,11 +1362,6 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
                 const int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
                 hipLaunchKernelGGL(k_queries_bf16, dim3(grid), dim3(256), 0, s, q64, nq, rnq_pad, dim, ldb, q16);
             }
-            // a live refiner of this scratch's previous sequence may still be polling (it reads cnt / cand, writes thr)
-            if (w.side && w.ev_join) {
-                const hipError_t ew = hipStreamWaitEvent(s, w.ev_join, 0);
-                if (ew != hipSuccess) return ew;
-            }
             hipError_t e2 = hipMemsetAsync(w.cnt, 0, (size_t)rnq_pad * sizeof(uint32_t), s);
             if (e2 != hipSuccess) return e2;
             // the launch plan (filter_plan.hpp): sample size and sampling grid, where the pass-1 stages end
@@ -1459,56 +1380,22 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
             const FilterPlan fp = filter_plan(n_rows, wg_cap, (uint32_t)RS_NWAVES, (uint32_t)MFMA_GROUPS, kn);
             const uint32_t sample_blocks = fp.sample_blocks, gx0 = fp.gx0, r_gpw = fp.gpw, r_groups = fp.groups;
             const uint64_t r_sample_rows = std::min<uint64_t>((uint64_t)sample_blocks * 32, n_rows);
-            int r_stages = fp.stages;
+            const int r_stages = fp.stages;
             const uint32_t* st_end = fp.st_end;
-            // Live refinement instead of stages (k_refine_live): when the staged form would relaunch AND the pass-1 grid
-            // leaves CUs idle for the refiner (config 3's shard: 253 workgroups on 256 CUs).  ONE pass-1 launch over all
-            // blocks; the refiner raises thr[] beside it.  VL_MFMA_LIVE=0 keeps the stages.
-            uint32_t live = 0, live_wgs = 0;
-            const uint32_t st_all[2] = {0u, fp.n_blocks};
-            {
-                int dev = 0, cus = 256;
-                (void)hipGetDevice(&dev);
-                if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-                const uint32_t gx1 = std::max<uint32_t>(1u, std::min<uint32_t>((fp.n_blocks + RS_NWAVES - 1) / RS_NWAVES, wg_cap));
-                const char* lv = getenv("VL_MFMA_LIVE");
-                const int want_live = lv && *lv ? atoi(lv) : 0;  // opt-in while it is being measured
-                if (want_live && r_stages >= 2 && w.side && w.ev_fork && w.ev_join && w.live_done &&
-                    gx1 * r_chunks < (uint32_t)cus) {
-                    live = 1;
-                    live_wgs = (uint32_t)cus - gx1 * r_chunks;  // one 256-thread refiner workgroup per idle CU ...
-                    live_wgs = std::min<uint32_t>(live_wgs * 4u, 16u);  // ... times four (they are tiny): 16 at most
-                    r_stages = 1;
-                    st_end = st_all;
-                    // the refiner trusts only WRITTEN entries of each buffer's head: pre-set it to all ones
-                    const hipError_t em = hipMemset2DAsync(w.cand, (size_t)MFMA_CAND_CAP * sizeof(Cand32), 0xFF,
-                                                           (size_t)LIVE_LOOK * sizeof(Cand32), nq, s);
-                    if (em != hipSuccess) return em;
-                    const hipError_t ed = hipMemsetAsync(w.live_done, 0, sizeof(uint32_t), s);
-                    if (ed != hipSuccess) return ed;
-                }
-            }
             bool r_launched = false;
 #define VL_RLAUNCH2(K, MET)                                                                                                     \
     {                                                                                                                           \
         hipLaunchKernelGGL((k_mfma_rows<K, 0, MET>), dim3(gx0, r_chunks), dim3(RS_NWAVES * 64), 0, s, slab, row_norm,           \
                            row_sqnorm, q16, nq, 0u, sample_blocks, (uint32_t)r_sample_rows, w.gmax, r_groups, r_gpw,            \
-                           (const float*)nullptr, (Cand32*)nullptr, (uint32_t*)nullptr, 0u, 0u, (uint32_t*)nullptr);            \
-        hipLaunchKernelGGL(k_thresholds, dim3((rnq_pad + 3) / 4), dim3(256), 0, s, w.gmax, r_groups, nq,                        \
-                           q64 + (size_t)nq * dim, w.thr, rnq_pad);                                                             \
+                           (const float*)nullptr, (Cand32*)nullptr, (uint32_t*)nullptr, 0u);                                    \
+        hipLaunchKernelGGL(k_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.gmax, r_groups, nq, q64 + (size_t)nq * dim,     \
+                           w.thr);                                                                                              \
         for (int st = 0; st < r_stages; ++st) {                                                                                 \
             const uint32_t tb = st_end[st], te = st_end[st + 1];                                                                \
             const uint32_t gx = std::max<uint32_t>(1u, std::min<uint32_t>((te - tb + RS_NWAVES - 1) / RS_NWAVES, wg_cap));      \
-            if (live) { /* the refiner starts once the sampled thresholds are in place and runs beside the scan */              \
-                (void)hipEventRecord(w.ev_fork, s);                                                                             \
-                (void)hipStreamWaitEvent(w.side, w.ev_fork, 0);                                                                 \
-                hipLaunchKernelGGL(k_refine_live, dim3(live_wgs), dim3(256), 0, w.side, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, \
-                                   nq, w.thr, w.live_done, gx * r_chunks * (uint32_t)RS_NWAVES, 2000000ull /* 20 ms */);       \
-                (void)hipEventRecord(w.ev_join, w.side);                                                                        \
-            }                                                                                                                   \
             hipLaunchKernelGGL((k_mfma_rows<K, 1, MET>), dim3(gx, r_chunks), dim3(RS_NWAVES * 64), 0, s, slab, row_norm,        \
                                row_sqnorm, q16, nq, tb, te, (uint32_t)n_rows, (int*)nullptr, 0u, 1u, w.thr, w.cand, w.cnt,      \
-                               (uint32_t)MFMA_CAND_CAP, live, w.live_done);                                                     \
+                               (uint32_t)MFMA_CAND_CAP);                                                                        \
             if (st + 1 < r_stages)                                                                                              \
                 hipLaunchKernelGGL(k_refine_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.cand, w.cnt,                     \
                                    (uint32_t)MFMA_CAND_CAP, nq, w.thr);                                                         \

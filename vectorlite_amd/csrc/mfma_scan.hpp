@@ -39,14 +39,9 @@ inline uint32_t mfma_ldb(uint32_t dim)
 struct MfmaScratch {
     void* q_bf16 = nullptr;     // [nq_pad_cap, ldb] bf16
     int* gmax = nullptr;        // [nq_cap, MFMA_GROUPS]
-    float* thr = nullptr;       // [nq_pad_cap] (+inf past the last query of a sequence)
+    float* thr = nullptr;       // [nq_cap]
     Cand32* cand = nullptr;     // [nq_cap, MFMA_CAND_CAP]
     uint32_t* cnt = nullptr;    // [nq_pad_cap]
-    // live threshold refinement (k_refine_live beside a pass-1 launch): a side stream, fork / join events, the counter
-    // the scanning waves report to.  All optional: without them the staged form runs.
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    uint32_t* live_done = nullptr;
     uint32_t nq_cap = 0;        // queries per launch sequence the buffers hold
     uint32_t nq_pad_cap = 0;    // ... rounded up to whole query chunks: rows of q_bf16 and cnt (the padding queries never produce candidates)
 };
