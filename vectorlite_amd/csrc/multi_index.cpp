@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <new>
 #include <string>
 #include <unordered_set>
 
@@ -26,6 +27,22 @@ struct PartOutcome {
         }
     }
 };
+
+// A part's call on a worker thread: whatever it throws (a host allocation inside the part) becomes that part's outcome --
+// an exception swallowed by the worker would leave the default rc = OK behind and the call would report success.
+template <typename F>
+void guarded(PartOutcome& o, F&& call)
+{
+    try {
+        o.capture(call());
+    } catch (const std::bad_alloc&) {
+        o.rc = ERR_OOM;
+        o.err = "host allocation failed in one part of the index";
+    } catch (...) {
+        o.rc = ERR_DEVICE;
+        o.err = "internal error in one part of the index";
+    }
+}
 
 int publish_first_error(const std::vector<PartOutcome>& o)
 {
@@ -160,7 +177,9 @@ int MultiFlatIndex::add_bulk(const uint64_t* ids, const double* values, uint64_t
     std::vector<PartOutcome> oc((size_t)P);
 
     if (mode_ == REPLICAS) {  // the same n sequential adds on every replica: identical state, identical outcome
-        run_parts([&](int i) { oc[(size_t)i].capture(parts_[(size_t)i]->add_bulk(ids, values, n, validate, values_on_device, src_device)); });
+        run_parts([&](int i) {
+            guarded(oc[(size_t)i], [&]() { return parts_[(size_t)i]->add_bulk(ids, values, n, validate, values_on_device, src_device); });
+        });
         return publish_first_error(oc);
     }
 
@@ -205,8 +224,10 @@ int MultiFlatIndex::add_bulk(const uint64_t* ids, const double* values, uint64_t
         const size_t p = (size_t)i;
         if (count[p] == 0) return;
         // ids were validated against the whole index above; the shard's own check keeps its id table current
-        oc[p].capture(parts_[p]->add_bulk(ids + start[p], values ? values + start[p] * dim_ : nullptr, count[p], validate,
-                                          values_on_device, src_device));
+        guarded(oc[p], [&]() {
+            return parts_[p]->add_bulk(ids + start[p], values ? values + start[p] * dim_ : nullptr, count[p], validate,
+                                       values_on_device, src_device);
+        });
     });
     for (int p = 0; p < P; ++p) {
         if (count[(size_t)p] == 0 || oc[(size_t)p].rc != OK) continue;
@@ -226,7 +247,7 @@ int MultiFlatIndex::remove(uint64_t id)
     const int P = (int)parts_.size();
     std::vector<PartOutcome> oc((size_t)P);
     std::vector<std::vector<uint64_t>> gone((size_t)P);
-    run_parts([&](int i) { oc[(size_t)i].capture(parts_[(size_t)i]->remove_report(id, &gone[(size_t)i])); });
+    run_parts([&](int i) { guarded(oc[(size_t)i], [&]() { return parts_[(size_t)i]->remove_report(id, &gone[(size_t)i]); }); });
     if (mode_ == ROW_SHARDS)
         for (int p = 0; p < P; ++p)
             for (uint64_t pos : gone[(size_t)p])  // descending: each erase leaves the earlier positions in place
@@ -301,10 +322,11 @@ int MultiFlatIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_
         const uint64_t q0 = std::min<uint64_t>(nq, per * (uint64_t)i), q1 = std::min<uint64_t>(nq, q0 + per);
         if (q0 == q1) return;
         // q_len may be wrong (then every part reports the mismatch before reading a query): offsets use the caller's q_len
-        oc[(size_t)i].capture(parts_[(size_t)i]->search_batch(queries ? queries + q0 * q_len : nullptr, q1 - q0, q_len, k, metric,
-                                                              out_pos ? out_pos + q0 * k : nullptr,
-                                                              out_ids ? out_ids + q0 * k : nullptr,
-                                                              out_scores ? out_scores + q0 * k : nullptr, out_n + q0));
+        guarded(oc[(size_t)i], [&]() {
+            return parts_[(size_t)i]->search_batch(queries ? queries + q0 * q_len : nullptr, q1 - q0, q_len, k, metric,
+                                                   out_pos ? out_pos + q0 * k : nullptr, out_ids ? out_ids + q0 * k : nullptr,
+                                                   out_scores ? out_scores + q0 * k : nullptr, out_n + q0);
+        });
         answered_[(size_t)i]->fetch_add(q1 - q0, std::memory_order_relaxed);
     });
     set_last_path(oc[0].path);
