@@ -186,3 +186,72 @@ def test_sharded_batch_on_the_mfma_path_matches_one_index():
     di, ds, dn = m.search_batch_device(dQ, 10, 0)
     wi, ws, wn = one.search_batch(Q, 10, 0)
     assert di.tolist() == wi.tolist() and ds.tolist() == ws.tolist()
+
+
+@pytest.mark.parametrize("mode", ["replicas", "row_shards"])
+def test_stateful_random_stream_on_a_three_part_handle(mode):
+    """A random stream of adds, unvalidated bulk adds that DUPLICATE live ids (FlatIndex::new keeps them,
+    src/index/flat.rs:68-73), deletes (present -- all copies go --, absent), refused adds and clones on a handle of three
+    parts; after every step the whole surface is compared with ONE oracle that received the same stream.  Row shards:
+    rows of one id end up on different GPUs, deletes close gaps on each, and the answer must still rank ties by the
+    insertion order of the whole index (src/index/flat.rs:94,116)."""
+    import vectorlite_amd as V
+    from oracle import oracle as O
+    rng = np.random.default_rng(20261004 + (mode == "row_shards"))
+    dim, n0 = 24, 700
+    base = _unit(rng, 40, dim)                      # few distinct directions: equal rows, ties everywhere
+    rows = base[rng.integers(0, 40, size=n0)]
+    ids = (np.arange(n0, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(5)) % np.uint64(2 ** 40)
+    m = V.MultiFlatIndex(dim, [0, 0, 0], mode)
+    m.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    live = ids.tolist()
+    next_id = 10 ** 12
+    for step in range(60):
+        op = int(rng.integers(0, 7))
+        if op == 0:
+            v = base[int(rng.integers(0, 40))] * float(rng.choice([1.0, 2.0]))
+            m.add(V.Vector(next_id, v)); ref.add(next_id, v); live.append(next_id); next_id += 1
+        elif op == 1:  # bulk add, validated
+            c = int(rng.integers(1, 40))
+            vs = base[rng.integers(0, 40, size=c)]
+            new = np.arange(next_id, next_id + c, dtype=np.uint64)
+            m.add_rows(new, vs)
+            for i in range(c):
+                ref.add(int(new[i]), vs[i])
+            live += new.tolist(); next_id += c
+        elif op == 2 and live:  # unvalidated bulk add that repeats live ids: duplicates are kept
+            c = int(rng.integers(1, 12))
+            dup = np.array([live[int(rng.integers(len(live)))] for _ in range(c)], dtype=np.uint64)
+            vs = _unit(rng, c, dim)
+            m.add_rows(dup, vs, validate=False)
+            ref.extend(dup, vs)
+            live += dup.tolist()
+        elif op == 3 and live:  # delete: every copy of the id goes, wherever it is stored
+            victim = live[int(rng.integers(len(live)))]
+            m.delete(victim); ref.delete(victim)
+            live = [x for x in live if x != victim]
+        elif op == 4:
+            m.delete(3); ref.delete(3)              # absent: Ok(())
+        elif op == 5 and live:
+            with pytest.raises(V.IndexOpError, match="already exists"):
+                m.add(V.Vector(live[0], base[0]))
+        else:
+            m = m.clone()
+        assert len(m) == len(ref) == len(live), (step, op)
+        if not live:
+            continue
+        metric = int(rng.integers(0, 4))
+        k = int(rng.choice([1, 7, 64, 100]))
+        q = base[int(rng.integers(0, 40))] + (0.0 if rng.random() < 0.5 else 1e-3) * _unit(rng, 1, dim)[0]
+        _same(m.search_arrays(q, k, metric), ref.search(q, k, metric))
+        probe = live[int(rng.integers(len(live)))]
+        assert np.array_equal(np.asarray(m.get_vector(probe).values), np.asarray(ref.get_vector(probe)))
+    e_ids, e_vals = m.export()
+    assert e_ids.tolist() == live
+    Q = base[:9] + 1e-3 * _unit(rng, 9, dim)
+    for metric in range(4):
+        bi, bs, bn = m.search_batch(Q, 10, metric)
+        for j in range(9):
+            wi, ws = ref.search(Q[j], 10, metric)
+            assert bi[j, : bn[j]].tolist() == wi.tolist() and bs[j, : bn[j]].tolist() == ws.tolist(), (metric, j)
