@@ -255,3 +255,48 @@ def test_stateful_random_stream_on_a_three_part_handle(mode):
         for j in range(9):
             wi, ws = ref.search(Q[j], 10, metric)
             assert bi[j, : bn[j]].tolist() == wi.tolist() and bs[j, : bn[j]].tolist() == ws.tolist(), (metric, j)
+
+
+@pytest.mark.parametrize("mode", ["row_shards", "replicas"])
+def test_concurrent_callers_of_single_and_batch_searches_on_a_three_part_handle(mode):
+    """Many readers at once (RwLock::read, src/client.rs:398): eight threads mix single searches and batches on one handle.
+    A sharded search borrows its own exchange slot (record block + merger) and, when the part workers are taken by another
+    call, walks its parts on the calling thread -- nobody queues behind one set of buffers, and every answer is the oracle's."""
+    import vectorlite_amd as V
+    from oracle import oracle as O
+    rng = np.random.default_rng(4242 + (mode == "replicas"))
+    dim, n = 48, 30000
+    rows = _unit(rng, n, dim)
+    rows[11000] = rows[3]
+    rows[29999] = rows[3]
+    ids = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(9)) % np.uint64(2 ** 44)
+    m = V.MultiFlatIndex(dim, [0, 0, 0], mode)
+    m.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    Q = _unit(rng, 40, dim)
+    Q[5] = rows[3]
+    want = {(qi, metric): ref.search(Q[qi], 10, metric) for qi in range(len(Q)) for metric in (0, 1)}
+    errors = []
+
+    def worker(t):
+        try:
+            for r in range(4):
+                metric = (t + r) % 2
+                if (t + r) % 3 == 0:  # a batch of 10
+                    q0 = (t * 5 + r * 7) % 30
+                    bi, bs, bn = m.search_batch(Q[q0: q0 + 10], 10, metric)
+                    for j in range(10):
+                        wi, ws = want[(q0 + j, metric)]
+                        assert bi[j, : bn[j]].tolist() == wi.tolist() and bs[j, : bn[j]].tolist() == ws.tolist(), (t, r, j)
+                else:
+                    for qi in range(t, len(Q), 8):
+                        _same(m.search_arrays(Q[qi], 10, metric), want[(qi, metric)])
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert errors == []
+    assert len(m) == n

@@ -117,10 +117,38 @@ MultiFlatIndex::~MultiFlatIndex()
         w->cv.notify_all();
         if (w->th.joinable()) w->th.join();
     }
-    if (h_records_) {
-        (void)hipSetDevice(parts_.empty() ? 0 : parts_[0]->device());
-        (void)hipHostFree(h_records_);
+    for (auto& sl : slots_)
+        if (sl && sl->h_records) {
+            (void)hipSetDevice(parts_.empty() ? 0 : parts_[0]->device());
+            (void)hipHostFree(sl->h_records);
+        }
+}
+
+MultiFlatIndex::ExchangeSlot* MultiFlatIndex::acquire_slot() const
+{
+    std::unique_lock<std::mutex> lk(slots_mu_);
+    for (;;) {
+        for (auto& sl : slots_)
+            if (!sl->busy) {
+                sl->busy = true;
+                return sl.get();
+            }
+        if (slots_.size() < EXCHANGE_SLOTS) {
+            slots_.emplace_back(new ExchangeSlot());
+            slots_.back()->busy = true;
+            return slots_.back().get();
+        }
+        slots_cv_.wait(lk);
     }
+}
+
+void MultiFlatIndex::release_slot(ExchangeSlot* s) const
+{
+    {
+        std::lock_guard<std::mutex> lk(slots_mu_);
+        s->busy = false;
+    }
+    slots_cv_.notify_one();
 }
 
 void MultiFlatIndex::run_parts(const std::function<void(int)>& fn) const
@@ -130,7 +158,19 @@ void MultiFlatIndex::run_parts(const std::function<void(int)>& fn) const
         fn(0);
         return;
     }
-    std::lock_guard<std::mutex> g(run_mu_);
+    // the workers serve one fan-out at a time; a caller that finds them taken (another search or a batch in flight) does not
+    // queue behind it: it walks its parts on its own thread -- every part's entry points are thread-safe and select their
+    // own device -- so concurrent callers keep all GPUs busy between them
+    std::unique_lock<std::mutex> g(run_mu_, std::try_to_lock);
+    if (!g.owns_lock()) {
+        for (int i = 0; i < P; ++i) {
+            try {
+                fn(i);
+            } catch (...) {
+            }
+        }
+        return;
+    }
     for (int i = 1; i < P; ++i) {
         Worker* w = workers_[(size_t)i - 1].get();
         {
@@ -382,31 +422,39 @@ int MultiFlatIndex::shard_search(const double* queries, uint64_t nq, uint64_t q_
         set_last_error("nq x k too large for one exchange");
         return ERR_INVALID_ARG;
     }
-    std::lock_guard<std::mutex> mg(merge_mu_);  // the record block and the merger are one set per handle
+    // the record block and the merger of THIS search (one set per search in flight)
+    ExchangeSlot* slot = acquire_slot();
+    struct SlotGuard {
+        const MultiFlatIndex* m;
+        ExchangeSlot* s;
+        ~SlotGuard() { m->release_slot(s); }
+    } slot_guard{this, slot};
     if (hipSetDevice(parts_[0]->device()) != hipSuccess) {
         (void)hipGetLastError();
         set_last_error("hipSetDevice failed");
         return ERR_DEVICE;
     }
-    if (words * (uint64_t)P > h_records_cap_) {
-        if (h_records_) (void)hipHostFree(h_records_);
-        h_records_ = nullptr;
-        h_records_cap_ = 0;
+    if (words * (uint64_t)P > slot->h_records_cap) {
+        if (slot->h_records) (void)hipHostFree(slot->h_records);
+        slot->h_records = nullptr;
+        slot->h_records_cap = 0;
         // portable: the shards' GPUs write nothing here, but their worker threads fill it while another device is current
-        if (hipHostMalloc(reinterpret_cast<void**>(&h_records_), words * (uint64_t)P * 8, hipHostMallocPortable) != hipSuccess) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&slot->h_records), words * (uint64_t)P * 8, hipHostMallocPortable) != hipSuccess) {
             (void)hipGetLastError();
             set_last_error("host allocation of the shard records failed");
             return ERR_OOM;
         }
-        h_records_cap_ = words * (uint64_t)P;
+        slot->h_records_cap = words * (uint64_t)P;
     }
-    if (!merger_) merger_.reset(new ShardMerger(parts_[0]->device()));
+    if (!slot->merger) slot->merger.reset(new ShardMerger(parts_[0]->device()));
+    unsigned long long* const recs = slot->h_records;
+    ShardMerger* const merger = slot->merger.get();
     // every shard answers the whole batch on its own rows; positions become global insertion numbers on the way
     std::vector<std::string> errs((size_t)P);
     std::vector<int> paths((size_t)P, PATH_NONE);
     run_parts([&](int i) {
         const size_t p = (size_t)i;
-        unsigned long long* rec = h_records_ + p * words;
+        unsigned long long* rec = recs + p * words;
         shard_search_local(parts_[p].get(), 0, UINT64_MAX, true, queries, nq, q_len, ks, metric, rec, false, seq_[p].data());
         if (rec[0] != 0) errs[p] = last_error();
         paths[p] = last_path();
@@ -417,7 +465,7 @@ int MultiFlatIndex::shard_search(const double* queries, uint64_t nq, uint64_t q_
     if (total >= 2)
         for (int p = 0; p < P; ++p) {
             if (lens[(size_t)p] != 1) continue;
-            const unsigned long long* rec = h_records_ + (size_t)p * words;
+            const unsigned long long* rec = recs + (size_t)p * words;
             if (rec[0] != 0) continue;
             const double* sc = reinterpret_cast<const double*>(rec + SHARD_HDR_WORDS + nq);
             for (uint64_t q = 0; q < nq; ++q)
@@ -426,7 +474,7 @@ int MultiFlatIndex::shard_search(const double* queries, uint64_t nq, uint64_t q_
                     return ERR_NAN_SCORE;
                 }
         }
-    const int rc = merger_->merge_host(h_records_, (uint32_t)P, nq, ks, k, out_pos, out_ids, out_scores, out_n);
+    const int rc = merger->merge_host(recs, (uint32_t)P, nq, ks, k, out_pos, out_ids, out_scores, out_n);
     if (rc != OK) {
         for (int p = 0; p < P; ++p)
             if (!errs[(size_t)p].empty()) {

@@ -99,7 +99,7 @@ private:
     const int mode_;
     std::vector<std::unique_ptr<GpuFlatIndex>> parts_;
     mutable std::vector<std::unique_ptr<Worker>> workers_;
-    mutable std::mutex run_mu_;  // one fan-out at a time uses the workers
+    mutable std::mutex run_mu_;  // one fan-out at a time uses the workers; a caller that finds them busy runs its parts itself
 
     mutable std::shared_mutex mu_;  // search: shared; add / delete: unique (RwLock, src/client.rs:333,383,398)
     // ROW_SHARDS: global insertion number of every row of every shard (ascending within a shard)
@@ -110,11 +110,21 @@ private:
     mutable std::vector<std::unique_ptr<std::atomic<uint64_t>>> answered_;  // searches each part has answered
     mutable std::atomic<uint32_t> rr_{0};
 
-    // ROW_SHARDS exchange: pinned host block of all parts' records + the merge on part 0's GPU
-    mutable std::mutex merge_mu_;
-    mutable std::unique_ptr<ShardMerger> merger_;
-    mutable unsigned long long* h_records_ = nullptr;  // pinned [parts][words]
-    mutable uint64_t h_records_cap_ = 0;
+    // ROW_SHARDS exchange: a pinned host block of all parts' records + a merger on part 0's GPU per search IN FLIGHT.
+    // The reference serves many readers at once (RwLock::read, src/client.rs:398): concurrent searches of a sharded handle
+    // borrow separate slots (up to EXCHANGE_SLOTS; then they wait for one) instead of queueing behind one set of buffers.
+    struct ExchangeSlot {
+        std::unique_ptr<ShardMerger> merger;
+        unsigned long long* h_records = nullptr;  // pinned [parts][words]
+        uint64_t h_records_cap = 0;
+        bool busy = false;
+    };
+    static constexpr size_t EXCHANGE_SLOTS = 4;
+    ExchangeSlot* acquire_slot() const;
+    void release_slot(ExchangeSlot* s) const;
+    mutable std::mutex slots_mu_;
+    mutable std::condition_variable slots_cv_;
+    mutable std::vector<std::unique_ptr<ExchangeSlot>> slots_;
 };
 
 }  // namespace vl
