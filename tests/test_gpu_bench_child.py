@@ -67,6 +67,8 @@ def test_bench_child_process_prints_the_whole_contract_line(steps, warmup):
     assert c3["n_gpus"] == 1 and c3["rows_per_rank"] == 20000 and c3["roofline"]["bound"] == "mfma" and c3["roofline"]["frac"] > 0
     assert c3["own_rows_match_single_search"] == "4/4" and c3["transport"].startswith("RCCL")
     assert set(c3["exchange_ms_per_batch"]) >= {"ncclAllGather", "merge_kernel_and_d2h", "local_search_host_clock"}
+    # the same batch taken from device memory (vl_shard_search_batch_dev): timed beside the host form, identical answer
+    assert c3["device_queries"]["identical_to_host_queries"] is True and c3["device_queries"]["ms_per_batch"] > 0
     c4 = oc["c4_hnsw"]
     assert c4["parity"].startswith("unpinned") and set(c4["data"]) == {"latent16", "iid_gaussian"}
     for dist_name in ("latent16", "iid_gaussian"):
