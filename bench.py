@@ -567,8 +567,33 @@ def run_c4(V, torch, args, dev, dev_index, k, cap_s, log_fn):
             tl = time.perf_counter()
             hn.search_arrays(Q[i % nq], k, 0)
             lat.append(time.perf_counter() - tl)
+        # BASELINE config 4's own words: "recall@10 vs CPU HNSW".  The graph is exported (vl_index_hnsw_graph_export) and
+        # oracle/vl_hnsw_cpu.c -- the checker's single-threaded walk with the reference's f64 -> u64 callbacks
+        # (src/index/hnsw.rs:113-174) -- walks the SAME graph at ef 128 on a few queries: its recall, its time per
+        # query, and the GPU walk's recall on the same queries.  (A CPU baseline leg: the oracle is the checker here.)
+        cpu_walk = None
+        try:
+            from oracle import oracle as O
+            n_cpu = min(nchk, 12)
+            graph = hn.graph(with_rows=True)
+            walker = O.HnswCpuWalker(graph, O.COSINE)
+            tw = time.perf_counter()
+            cw = [walker.search(Q[i], 128, k) for i in range(n_cpu)]
+            t_cpu = (time.perf_counter() - tw) / n_cpu
+            gi, _, gn = hn.search_batch(Q[:n_cpu], k, 0, ef=128)
+            in_top = lambda i, ids_: sum(1 for x in ids_ if D[i][int(x)] <= kth[i]) / float(k)  # noqa: E731
+            cpu_walk = {"queries": n_cpu, "ef": 128, "cores": 1,
+                        "cpu_recall_at_10_vs_u64_distance_order": round(float(np.mean([in_top(i, cw[i][0]) for i in range(n_cpu)])), 4),
+                        "gpu_recall_at_10_same_queries": round(float(np.mean([in_top(i, gi[i, :int(gn[i])]) for i in range(n_cpu)])), 4),
+                        "cpu_ms_per_query": round(t_cpu * 1e3, 3),
+                        "cpu_distance_evals_per_query": round(walker.evals.value / n_cpu, 1),
+                        "walker": "oracle/vl_hnsw_cpu.c on the graph this index built (parity with crate hnsw 0.11.0's walk: unpinned)"}
+            del walker, graph
+        except Exception as e:  # noqa: BLE001 -- the recall / QPS figures above stand without it
+            cpu_walk = {"skipped": f"{type(e).__name__}: {e}"[:200]}
         res["data"][name] = {"build_s": round(t_build, 2), "inserts_per_s": round(n / t_build, 0),
-                             "single_query_ms_strict_beam": round(float(np.median(lat)) * 1e3, 3), **per_ef}
+                             "single_query_ms_strict_beam": round(float(np.median(lat)) * 1e3, 3), **per_ef,
+                             "cpu_hnsw_walk_same_graph": cpu_walk}
         log_fn(f"[bench] config 4 / {name}: build {t_build:.1f}s, " + ", ".join(f"{e}: {v['recall_at_10_vs_exact_f64_order']:.3f} @ {v['queries_per_s']:.0f} q/s" for e, v in per_ef.items()))
         del flat, hn, A
         torch.cuda.empty_cache()

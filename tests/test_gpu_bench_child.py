@@ -76,6 +76,10 @@ def test_bench_child_process_prints_the_whole_contract_line(steps, warmup):
         for ef in ("ef10", "ef32", "ef128"):
             assert 0.0 <= d[ef]["recall_at_10_vs_exact_f64_order"] <= 1.0 and d[ef]["roofline"]["frac"] >= 0
         assert d["ef128"]["recall_at_10_vs_exact_f64_order"] >= d["ef10"]["recall_at_10_vs_exact_f64_order"] - 0.05
+        cw = d["cpu_hnsw_walk_same_graph"]   # config 4's "recall@10 vs CPU HNSW": the checker's walk of the exported graph
+        assert "skipped" not in cw, cw
+        assert cw["cores"] == 1 and cw["cpu_ms_per_query"] > 0 and 0.0 <= cw["cpu_recall_at_10_vs_u64_distance_order"] <= 1.0
+        assert abs(cw["cpu_recall_at_10_vs_u64_distance_order"] - cw["gpu_recall_at_10_same_queries"]) <= 0.25
     full = cb["full_size_check"]
     assert full["ran"] is True and full["gpu_answer_bit_identical"].startswith("2/2")
     assert rf["kernel_variant"]["query_in_kernarg"] == 1
