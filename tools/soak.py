@@ -64,6 +64,19 @@ while time.time() < t_end:
         si, ss, sn = sh.search_batch(Q[:16], 10, 0); searches += 16
         assert si[0].tolist() == b[0][0].tolist() and ss[0].tolist() == b[1][0].tolist()
         comm.close(); del sh, comm
+    # one handle over three parts (vl_flat_create_multi; the parts share this card): worker threads, exchange slots and
+    # mergers are created and torn down every round; concurrent callers make it grow to several slots
+    for mode in ("replicas", "row_shards"):
+        mh = V.MultiFlatIndex(dim, [0, 0, 0], mode)
+        nm = min(n, 6000)
+        mh.add_rows(np.arange(nm, dtype=np.uint64), rows[:nm], validate=False)
+        mb = mh.search_batch(Q, 10, 0); searches += 40
+        mt = [threading.Thread(target=lambda t=t: [mh.search_arrays(Q[(t * 3 + j) % 40], 10, 0) for j in range(4)]) for t in range(6)]
+        [x.start() for x in mt]; mh.search_batch(Q[:12], 10, 1); [x.join() for x in mt]; searches += 36
+        one = mh.search_arrays(Q[4], 10, 0)
+        assert mb[0][4].tolist() == one[0].tolist() and mb[1][4].tolist() == one[1].tolist()
+        mc = mh.clone(); mc.delete(5); assert len(mc) == nm - 1 and len(mh) == nm
+        del mh, mc
     del idx, c
     gc.collect()
     torch.cuda.synchronize()
