@@ -24,7 +24,7 @@ def _same(got, want):
 
 
 @pytest.mark.parametrize("mode", ["replicas", "row_shards"])
-@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0], [0] * 8])  # eight parts: the shape of one 8-GPU node
 def test_trait_surface_matches_one_oracle(mode, devices):
     import vectorlite_amd as V
     from oracle import oracle as O
