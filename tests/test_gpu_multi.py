@@ -293,10 +293,13 @@ def test_concurrent_callers_of_single_and_batch_searches_on_a_three_part_handle(
                         _same(m.search_arrays(Q[qi], 10, metric), want[(qi, metric)])
         except Exception as e:  # noqa: BLE001
             errors.append(repr(e))
-    th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    assert errors == []
+    for coalesce in (False, True):   # second round: every part coalesces its concurrent single searches into shared slab passes
+        if coalesce:
+            m.set_coalescing(32, 100)
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert errors == [], (coalesce, errors)
     assert len(m) == n
