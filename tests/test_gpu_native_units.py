@@ -49,3 +49,29 @@ def test_search_cap_bounds_the_write_while_another_thread_grows_the_index(tmp_pa
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().endswith("ok"), r.stdout
+
+
+def test_a_failed_device_allocation_leaves_the_handle_and_the_thread_usable():
+    """reserve() of far more rows than the card holds must fail with the out-of-memory status and NOTHING else: the
+    failed hipMalloc leaves HIP's per-thread sticky error behind, and the next kernel launch of this thread used to
+    report it as its own ("launch_scan(...): out of memory" from a search on a perfectly healthy index)."""
+    import numpy as np
+    import vectorlite_amd as V
+    rows = np.random.default_rng(1).standard_normal((1000, 384))
+    idx = V.FlatIndex(384)
+    idx.add_rows(np.arange(1000, dtype=np.uint64), rows)
+    with pytest.raises(V.VectorLiteError) as ei:
+        idx.reserve(1_000_000_000)          # 3 TB of f64 rows
+    assert "memory" in str(ei.value).lower(), str(ei.value)
+    r = idx.search(rows[5], 3, 0)           # same thread, next launch
+    assert r[0].id == 5 and len(idx) == 1000
+    idx.add(V.Vector(5000, rows[3] * 2.0))
+    assert len(idx) == 1001
+    hn = V.HNSWIndex(384, 0)                # another handle on the same thread
+    hn.add_rows(np.arange(500, dtype=np.uint64), rows[:500])
+    assert hn.search(rows[9], 1, 0)[0].id == 9
+    m = V.MultiFlatIndex(384, [0, 0], "row_shards")
+    with pytest.raises(V.VectorLiteError):
+        m.reserve(2_000_000_000)
+    m.add_rows(np.arange(1000, dtype=np.uint64), rows)
+    assert len(m) == 1000 and m.search(rows[7], 1, 0)[0].id == 7

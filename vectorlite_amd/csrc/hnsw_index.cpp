@@ -17,6 +17,7 @@ namespace vl {
         hipError_t e_ = (expr);                                                                  \
         if (e_ != hipSuccess) {                                                                  \
             set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_));                   \
+            (void)hipGetLastError(); /* a failed call (hipMalloc out of memory ...) leaves the thread's sticky error behind: the next launch's hipGetLastError() must not report it */ \
             return (e_ == hipErrorOutOfMemory) ? (int)ERR_OOM : (int)ERR_DEVICE;                 \
         }                                                                                        \
     } while (0)

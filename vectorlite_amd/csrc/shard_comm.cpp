@@ -22,6 +22,7 @@ static_assert(sizeof(unsigned long long) == sizeof(uint64_t) && sizeof(double) =
         hipError_t e_ = (expr);                                                       \
         if (e_ != hipSuccess) {                                                       \
             set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_));        \
+            (void)hipGetLastError(); /* a failed call (hipMalloc out of memory ...) leaves the thread's sticky error behind: the next launch's hipGetLastError() must not report it */ \
             return (e_ == hipErrorOutOfMemory) ? (int)ERR_OOM : (int)ERR_DEVICE;      \
         }                                                                             \
     } while (0)
@@ -292,6 +293,7 @@ int ShardComm::fail_and_abort(int rc)
         hipError_t e_ = (expr);                                                       \
         if (e_ != hipSuccess) {                                                       \
             set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_));        \
+            (void)hipGetLastError(); /* a failed call (hipMalloc out of memory ...) leaves the thread's sticky error behind: the next launch's hipGetLastError() must not report it */ \
             return fail_and_abort((e_ == hipErrorOutOfMemory) ? (int)ERR_OOM : (int)ERR_DEVICE); \
         }                                                                             \
     } while (0)
