@@ -197,13 +197,13 @@ GpuFlatIndex::~GpuFlatIndex()
 
 uint64_t GpuFlatIndex::len() const
 {
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     return ids_.size();
 }
 
 int GpuFlatIndex::reserve(uint64_t n_rows)
 {
-    std::unique_lock<std::shared_mutex> lk(mu_);
+    std::unique_lock<RwLock> lk(mu_);
     VL_HIP(hipSetDevice(device_));
     return ensure_capacity(n_rows);
 }
@@ -325,7 +325,7 @@ int GpuFlatIndex::add_bulk(const uint64_t* ids, const double* values, uint64_t n
 {
     if (n == 0) return OK;
     if (!ids || (!values && dim_)) return ERR_INVALID_ARG;
-    std::unique_lock<std::shared_mutex> lk(mu_);
+    std::unique_lock<RwLock> lk(mu_);
     VL_HIP(hipSetDevice(device_));
 
     uint64_t n_take = n;
@@ -415,7 +415,7 @@ int GpuFlatIndex::remove(uint64_t id) { return remove_report(id, nullptr); }
 
 bool GpuFlatIndex::contains(uint64_t id) const
 {
-    std::unique_lock<std::shared_mutex> lk(mu_);  // may rebuild the table
+    std::unique_lock<RwLock> lk(mu_);  // may rebuild the table
     if (!id_counts_valid_) rebuild_id_counts();
     auto it = id_counts_.find(id);
     return it != id_counts_.end() && it->second > 0;
@@ -423,7 +423,7 @@ bool GpuFlatIndex::contains(uint64_t id) const
 
 int GpuFlatIndex::find_first(uint64_t id, uint64_t* out_pos) const
 {
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     auto it = std::find(ids_.begin(), ids_.end(), id);
     if (it == ids_.end()) return ERR_NOT_FOUND;
     if (out_pos) *out_pos = (uint64_t)(it - ids_.begin());
@@ -433,7 +433,7 @@ int GpuFlatIndex::find_first(uint64_t id, uint64_t* out_pos) const
 int GpuFlatIndex::get_row_at(uint64_t pos, double* out) const
 {
     if (!out && dim_) return ERR_INVALID_ARG;
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     if (pos >= ids_.size()) return ERR_NOT_FOUND;
     if (dim_) {
         VL_HIP(hipSetDevice(device_));
@@ -444,7 +444,7 @@ int GpuFlatIndex::get_row_at(uint64_t pos, double* out) const
 
 int GpuFlatIndex::remove_report(uint64_t id, std::vector<uint64_t>* removed_positions)
 {
-    std::unique_lock<std::shared_mutex> lk(mu_);
+    std::unique_lock<RwLock> lk(mu_);
     VL_HIP(hipSetDevice(device_));
     // retain(|e| e.id != id): every matching row goes, highest position first
     for (uint64_t p = ids_.size(); p-- > 0;) {
@@ -547,7 +547,7 @@ int GpuFlatIndex::search_coalesced(const double* query, uint64_t q_len, uint64_t
     if (!out_n) return ERR_INVALID_ARG;
     *out_n = 0;
     {   // everything that can fail or finish without touching the slab is settled on the calling thread
-        std::shared_lock<std::shared_mutex> lk(mu_);
+        std::shared_lock<RwLock> lk(mu_);
         const uint64_t n = ids_.size();
         if (metric < 0 || metric > 3 || (n != 0 && q_len != dim_) || n == 0 || k == 0 || (!query && dim_) || !out_scores ||
             force_path_.load() != 0)
@@ -581,7 +581,7 @@ void GpuFlatIndex::run_coalesced(std::vector<CoalesceReq*>& batch) const
     // k = 2^63 with two queries would wrap nq * k to 0 (mutators are exclusive, so len cannot move under a search)
     uint64_t n_rows;
     {
-        std::shared_lock<std::shared_mutex> lk(mu_);
+        std::shared_lock<RwLock> lk(mu_);
         n_rows = ids_.size();
     }
     const uint64_t nq = batch.size(), k = std::min<uint64_t>(batch[0]->k, n_rows);
@@ -623,7 +623,7 @@ int GpuFlatIndex::search_direct(const double* query, uint64_t q_len, uint64_t k,
         set_last_error("unknown metric");
         return ERR_INVALID_ARG;
     }
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     const uint64_t n = ids_.size();
     if (n != 0 && q_len != dim_) {  // :99-104 (skipped while the index is empty)
         set_dim_mismatch(dim_, q_len);
@@ -659,7 +659,7 @@ int GpuFlatIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_le
         set_last_error("unknown metric");
         return ERR_INVALID_ARG;
     }
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     return search_batch_locked(queries, nq, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
 }
 
@@ -1310,7 +1310,7 @@ int GpuFlatIndex::search_batch_device(const double* d_queries, uint64_t nq, uint
         }
         return search_batch(d_queries ? h.data() : nullptr, nq, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
     };
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     const uint64_t n = ids_.size();
     // the checks of search_batch(), before any byte of the queries is touched (src/index/flat.rs:99-104: an empty index
     // accepts any query length)
@@ -1389,7 +1389,7 @@ int GpuFlatIndex::search_batch_device(const double* d_queries, uint64_t nq, uint
 int GpuFlatIndex::get_vector(uint64_t id, double* out) const
 {
     if (!out && dim_) return ERR_INVALID_ARG;
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     auto it = std::find(ids_.begin(), ids_.end(), id);  // first match (src/index/flat.rs:129-131)
     if (it == ids_.end()) return ERR_NOT_FOUND;
     const uint64_t pos = (uint64_t)(it - ids_.begin());
@@ -1403,7 +1403,7 @@ int GpuFlatIndex::get_vector(uint64_t id, double* out) const
 int GpuFlatIndex::max_id(uint64_t* out) const
 {
     if (!out) return ERR_INVALID_ARG;
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     if (ids_.empty()) return ERR_NOT_FOUND;
     *out = *std::max_element(ids_.begin(), ids_.end());
     return OK;
@@ -1411,7 +1411,7 @@ int GpuFlatIndex::max_id(uint64_t* out) const
 
 int GpuFlatIndex::export_rows(uint64_t* out_ids, double* out_values) const
 {
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     const uint64_t n = ids_.size();
     if (n == 0) return OK;
     if (!out_ids || (!out_values && dim_)) return ERR_INVALID_ARG;
@@ -1427,7 +1427,7 @@ int GpuFlatIndex::clone(GpuFlatIndex** out) const
 {
     if (!out) return ERR_INVALID_ARG;
     *out = nullptr;
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     GpuFlatIndex* c = nullptr;
     VL_TRY(create(dim_, device_, &c));
     std::unique_ptr<GpuFlatIndex> guard(c);
@@ -1445,7 +1445,7 @@ int GpuFlatIndex::hnsw_distances(const double* query, uint64_t q_len, int metric
                                  uint64_t m, uint64_t* out) const
 {
     if (metric < 0 || metric > 3) return ERR_INVALID_ARG;
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     if (q_len != dim_) {
         set_dim_mismatch(dim_, q_len);
         set_last_error("Dimension mismatch: expected " + std::to_string(dim_) + ", got " + std::to_string(q_len));

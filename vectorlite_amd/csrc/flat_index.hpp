@@ -18,6 +18,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "rwlock.hpp"
 #include "coalescer.hpp"
 #include "kernels.hpp"
 #include "mfma_scan.hpp"
@@ -205,7 +206,7 @@ private:
     const uint32_t ld_;  // slab row stride in floats: dim rounded up to 4 (16-byte vector loads)
     const int device_;
 
-    mutable std::shared_mutex mu_;  // search: shared; add/delete: unique
+    mutable RwLock mu_;  // search: shared; add/delete: unique
     // device storage
     double* d_master_ = nullptr;  // [cap, dim] f64: exact rows
     float* d_slab_ = nullptr;     // [cap, ld]  f32: what the scan streams

@@ -127,7 +127,7 @@ HnswIndex::~HnswIndex()
 
 uint64_t HnswIndex::len() const
 {
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     return live_count_;
 }
 
@@ -359,7 +359,7 @@ int HnswIndex::add_bulk(const uint64_t* ids, const double* values, uint64_t n, b
 {
     if (n == 0) return OK;
     if (!ids || !values) return ERR_INVALID_ARG;
-    std::unique_lock<std::shared_mutex> lk(mu_);
+    std::unique_lock<RwLock> lk(mu_);
     VL_HIP(hipSetDevice(device_));
 
     // n sequential add() calls: stop at the first id that already exists (:368-370)
@@ -466,7 +466,7 @@ int HnswIndex::add_bulk(const uint64_t* ids, const double* values, uint64_t n, b
 
 int HnswIndex::remove(uint64_t id)
 {
-    std::unique_lock<std::shared_mutex> lk(mu_);
+    std::unique_lock<RwLock> lk(mu_);
     auto it = id_to_node_.find(id);
     if (it == id_to_node_.end()) {  // :401-403
         set_last_error("Vector ID " + std::to_string(id) + " does not exist");
@@ -484,7 +484,7 @@ int HnswIndex::remove(uint64_t id)
 
 int HnswIndex::get_vector(uint64_t id, double* out) const
 {
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     auto it = id_to_node_.find(id);
     if (it == id_to_node_.end()) return ERR_NOT_FOUND;
     VL_HIP(hipSetDevice(device_));
@@ -509,7 +509,7 @@ int HnswIndex::clone(HnswIndex** out) const
 {
     if (!out) return ERR_INVALID_ARG;
     *out = nullptr;
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     VL_HIP(hipSetDevice(device_));
     std::unique_ptr<HnswIndex> c(new HnswIndex(dim_, metric_, params_, device_));
     GpuFlatIndex* st = nullptr;
@@ -553,7 +553,7 @@ int HnswIndex::clone(HnswIndex** out) const
 
 int HnswIndex::export_rows(uint64_t* out_ids, double* out_values) const
 {
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     if (live_count_ == 0) return OK;
     if (!out_ids || !out_values) return ERR_INVALID_ARG;
     VL_HIP(hipSetDevice(device_));
@@ -576,7 +576,7 @@ int HnswIndex::export_rows(uint64_t* out_ids, double* out_values) const
 void HnswIndex::graph_info(uint64_t* n_nodes, uint32_t* entry, int* max_level, uint32_t* m, uint32_t* m0,
                            uint64_t* upper_slots) const
 {
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     if (n_nodes) *n_nodes = n_nodes_;
     if (entry) *entry = entry_;
     if (max_level) *max_level = max_level_;
@@ -588,7 +588,7 @@ void HnswIndex::graph_info(uint64_t* n_nodes, uint32_t* entry, int* max_level, u
 int HnswIndex::graph_export(uint8_t* level, uint32_t* upper_off, uint32_t* cnt0, uint32_t* nbr0, uint32_t* cntU,
                             uint32_t* nbrU, uint64_t* node_ids, uint8_t* live, double* rows) const
 {
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     const uint64_t n = n_nodes_;
     if (n == 0) return OK;
     VL_HIP(hipSetDevice(device_));
@@ -606,7 +606,7 @@ int HnswIndex::graph_export(uint8_t* level, uint32_t* upper_off, uint32_t* cnt0,
 
 int HnswIndex::max_id(uint64_t* out) const
 {
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     if (id_to_node_.empty()) return ERR_NOT_FOUND;
     uint64_t m = 0;
     for (const auto& kv : id_to_node_) m = std::max(m, kv.first);
@@ -641,10 +641,10 @@ int HnswIndex::ensure_io(WalkScratch* ws, uint64_t nq, uint64_t k) const
     return OK;
 }
 
+// the caller holds mu_ (shared): search_batch's queries whose beam would exceed the walk kernel's
 int HnswIndex::search_exact_fallback(const double* query, uint64_t k, uint64_t* out_ids, double* out_scores,
                                      uint64_t* out_n) const
 {
-    std::shared_lock<std::shared_mutex> lk(mu_);
     *out_n = 0;
     if (live_count_ == 0) return OK;
     // every tombstoned node could sit in front of a live one: ask for that many more
@@ -728,7 +728,7 @@ int HnswIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_len, 
     if (!out_n && nq) return ERR_INVALID_ARG;
     for (uint64_t i = 0; i < nq; ++i) out_n[i] = 0;
     if (metric < 0 || metric > 3) return ERR_INVALID_ARG;
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     if (q_len != dim_) {  // :416-421, checked even when the index is empty
         set_dim_mismatch(dim_, q_len);
         set_last_error("Dimension mismatch: expected " + std::to_string(dim_) + ", got " + std::to_string(q_len));

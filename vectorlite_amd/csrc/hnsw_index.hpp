@@ -12,6 +12,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "rwlock.hpp"
 #include "flat_index.hpp"
 #include "hnsw.hpp"
 
@@ -111,7 +112,7 @@ private:
     const HnswParams params_;
     const int device_;
     std::unique_ptr<GpuFlatIndex> store_;
-    mutable std::shared_mutex mu_;
+    mutable RwLock mu_;
     hipStream_t stream_ = nullptr;  // mutators (graph growth, level upload, tombstones)
     mutable std::mutex pool_mu_;
     mutable std::condition_variable pool_cv_;

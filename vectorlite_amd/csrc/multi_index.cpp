@@ -211,7 +211,7 @@ int MultiFlatIndex::add_bulk(const uint64_t* ids, const double* values, uint64_t
 {
     if (n == 0) return OK;
     if (!ids || (!values && dim_)) return ERR_INVALID_ARG;
-    std::unique_lock<std::shared_mutex> lk(mu_);
+    std::unique_lock<RwLock> lk(mu_);
     const int P = (int)parts_.size();
     if (values_on_device && src_device < 0) src_device = parts_[0]->device();
     std::vector<PartOutcome> oc((size_t)P);
@@ -283,7 +283,7 @@ int MultiFlatIndex::add_bulk(const uint64_t* ids, const double* values, uint64_t
 
 int MultiFlatIndex::remove(uint64_t id)
 {
-    std::unique_lock<std::shared_mutex> lk(mu_);
+    std::unique_lock<RwLock> lk(mu_);
     const int P = (int)parts_.size();
     std::vector<PartOutcome> oc((size_t)P);
     std::vector<std::vector<uint64_t>> gone((size_t)P);
@@ -318,7 +318,7 @@ int MultiFlatIndex::search(const double* query, uint64_t q_len, uint64_t k, int 
                            double* out_scores, uint64_t* out_n) const
 {
     if (!out_n) return ERR_INVALID_ARG;
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     if (mode_ == REPLICAS) {
         const int i = pick_replica();
         inflight_[(size_t)i]->fetch_add(1, std::memory_order_relaxed);
@@ -345,7 +345,7 @@ int MultiFlatIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_
         set_last_error("unknown metric");
         return ERR_INVALID_ARG;
     }
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     if (mode_ == ROW_SHARDS) return shard_search(queries, nq, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
 
     // REPLICAS: one contiguous run of queries per replica (row stride k in every output, so the runs are plain offsets)
@@ -495,7 +495,7 @@ int MultiFlatIndex::shard_search(const double* queries, uint64_t nq, uint64_t q_
 // ---------------------------------------------------------------------------------------------
 uint64_t MultiFlatIndex::len() const
 {
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     if (mode_ == REPLICAS) return parts_[0]->len();
     uint64_t n = 0;
     for (auto& p : parts_) n += p->len();
@@ -504,7 +504,7 @@ uint64_t MultiFlatIndex::len() const
 
 int MultiFlatIndex::get_vector(uint64_t id, double* out) const
 {
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     if (mode_ == REPLICAS) return parts_[0]->get_vector(id, out);
     // the first row with that id in insertion order (src/index/flat.rs:129-131), whichever shard holds it
     int best = -1;
@@ -525,7 +525,7 @@ int MultiFlatIndex::get_vector(uint64_t id, double* out) const
 int MultiFlatIndex::max_id(uint64_t* out) const
 {
     if (!out) return ERR_INVALID_ARG;
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     if (mode_ == REPLICAS) return parts_[0]->max_id(out);
     bool any = false;
     uint64_t mx = 0;
@@ -543,7 +543,7 @@ int MultiFlatIndex::max_id(uint64_t* out) const
 
 int MultiFlatIndex::reserve(uint64_t n_rows)
 {
-    std::unique_lock<std::shared_mutex> lk(mu_);
+    std::unique_lock<RwLock> lk(mu_);
     const uint64_t P = parts_.size();
     const uint64_t per = mode_ == REPLICAS ? n_rows : (n_rows + P - 1) / P;
     for (auto& p : parts_) {
@@ -555,7 +555,7 @@ int MultiFlatIndex::reserve(uint64_t n_rows)
 
 int MultiFlatIndex::export_rows(uint64_t* out_ids, double* out_values) const
 {
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     if (mode_ == REPLICAS) return parts_[0]->export_rows(out_ids, out_values);
     // storage order of the whole index = ascending insertion number: rank every shard's rows in the union
     const size_t P = parts_.size();
@@ -593,7 +593,7 @@ int MultiFlatIndex::clone(MultiFlatIndex** out) const
 {
     if (!out) return ERR_INVALID_ARG;
     *out = nullptr;
-    std::shared_lock<std::shared_mutex> lk(mu_);
+    std::shared_lock<RwLock> lk(mu_);
     std::unique_ptr<MultiFlatIndex> m(new MultiFlatIndex(dim_, mode_));
     for (auto& p : parts_) {
         GpuFlatIndex* c = nullptr;

@@ -31,6 +31,7 @@
 #include <thread>
 #include <vector>
 
+#include "rwlock.hpp"
 #include "flat_index.hpp"
 #include "shard.hpp"
 
@@ -101,7 +102,7 @@ private:
     mutable std::vector<std::unique_ptr<Worker>> workers_;
     mutable std::mutex run_mu_;  // one fan-out at a time uses the workers; a caller that finds them busy runs its parts itself
 
-    mutable std::shared_mutex mu_;  // search: shared; add / delete: unique (RwLock, src/client.rs:333,383,398)
+    mutable RwLock mu_;  // search: shared; add / delete: unique (RwLock, src/client.rs:333,383,398)
     // ROW_SHARDS: global insertion number of every row of every shard (ascending within a shard)
     std::vector<std::vector<uint64_t>> seq_;
     uint64_t next_seq_ = 0;
