@@ -75,3 +75,22 @@ def test_a_failed_device_allocation_leaves_the_handle_and_the_thread_usable():
         m.reserve(2_000_000_000)
     m.add_rows(np.arange(1000, dtype=np.uint64), rows)
     assert len(m) == 1000 and m.search(rows[7], 1, 0)[0].id == 7
+
+
+def test_a_rejected_device_ordinal_does_not_poison_the_next_call():
+    """Creating a handle on a device that does not exist fails -- and used to leave HIP's sticky per-thread error behind
+    (the destructor of the half-made handle selects the bad ordinal), so the NEXT healthy call of the thread reported
+    'invalid device ordinal' from its first kernel launch.  Every ABI entry point now starts from a clean error slate."""
+    import numpy as np
+    import vectorlite_amd as V
+    rows = np.random.default_rng(2).standard_normal((200, 16))
+    for make in (lambda: V.FlatIndex(16, device=7), lambda: V.HNSWIndex(16, 0, device=7),
+                 lambda: V.MultiFlatIndex(16, [0, 9], "replicas"), lambda: V.MultiFlatIndex(16, [], "row_shards")):
+        with pytest.raises(V.VectorLiteError):
+            make()
+        idx = V.FlatIndex(16)
+        idx.add_rows(np.arange(200, dtype=np.uint64), rows)      # first launches after the failure
+        assert idx.search(rows[3], 2, 0)[0].id == 3
+    # absurd k: min(k, len) results, no allocation sized by the caller's k
+    assert len(idx.search_arrays(rows[3], 2 ** 63, 0)[0]) == 200
+    assert idx.search_batch(rows[:3], 2 ** 62, 0)[2].tolist() == [200, 200, 200]

@@ -31,6 +31,10 @@ constexpr int VL_ABI_VERSION = 1;
 template <typename F>
 int guarded(F&& f)
 {
+    // HIP keeps a sticky per-thread error: a call that failed earlier on this thread -- in this library (a reservation
+    // beyond the card, a device ordinal that does not exist) or in the host application -- would be reported by the
+    // next kernel launch's hipGetLastError() as that launch's own failure.  Every entry point starts from a clean slate.
+    (void)hipGetLastError();
     try {
         return f();
     } catch (const std::bad_alloc&) {
