@@ -61,7 +61,26 @@ def deleter():
     except Exception as e:  # noqa: BLE001
         errors.append(("deleter", repr(e)))
 
-th = [threading.Thread(target=searcher, args=(t,)) for t in range(4)]
+def cloner():   # Clone (src/persistence.rs:118 clones the index to save it), export and point lookups beside the writers
+    r = np.random.default_rng(77)
+    n_c = 0
+    try:
+        while not stop:
+            c = idx.clone()
+            q = rows[int(r.integers(0, n0))]
+            gi, gs = c.search_arrays(q, 5, metric)
+            assert len(gi) <= 5 and all(int(x) in universe for x in gi)
+            e_ids, e_vals = c.export()
+            assert len(e_ids) == len(c) and e_vals.shape[0] == len(e_ids)
+            v = idx.get_vector(int(r.integers(0, n0)))       # may have been deleted meanwhile: None is fine
+            assert v is None or len(v.values) == dim
+            del c
+            n_c += 1
+    except Exception as e:  # noqa: BLE001
+        errors.append(("cloner", repr(e)))
+    counts["clones"] = n_c
+tc = threading.Thread(target=cloner)
+th = [threading.Thread(target=searcher, args=(t,)) for t in range(4)] + [tc]
 wa, wd = threading.Thread(target=adder), threading.Thread(target=deleter)
 t0 = time.time()
 [x.start() for x in th]; wa.start(); wd.start()
@@ -69,7 +88,7 @@ wa.join(timeout=300); wd.join(timeout=300)
 stop = True
 [x.join(timeout=60) for x in th]
 hung = [x.is_alive() for x in th + [wa, wd]]
-print(f"{kind}: {sum(counts.values())} searches beside {len(added)} adds and {len(deleted)} deletes in {time.time() - t0:.1f}s; errors {errors[:3]}; hung {sum(hung)}")
+print(f"{kind}: {sum(v for k2, v in counts.items() if k2 != 'clones')} searches and {counts.get('clones', 0)} clone + export rounds beside {len(added)} adds and {len(deleted)} deletes in {time.time() - t0:.1f}s; errors {errors[:3]}; hung {sum(hung)}")
 assert not errors and not any(hung)
 assert len(idx) == n0 + 600 - 300
 if kind != "hnsw":   # final state against the oracle (flat semantics: bit for bit)
