@@ -10,6 +10,7 @@
 #include <chrono>
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <cstring>
 
@@ -215,52 +216,9 @@ int GpuFlatIndex::ensure_capacity(uint64_t rows)
         set_last_error("row count exceeds the u32 position space");
         return ERR_INVALID_ARG;
     }
-    uint64_t grown = cap_ < (1ull << 20) ? cap_ * 2 : cap_ + cap_ / 2;
-    uint64_t new_cap = std::max<uint64_t>({rows, grown, 1024});
-    double* m = nullptr;
-    float* s = nullptr;
-    float* inv = nullptr;
-    uint8_t* fl = nullptr;
-    const uint64_t dim_alloc = dim_ ? dim_ : 1;
-    int rc = dev_alloc(&m, new_cap * dim_alloc);
-    if (rc == OK) rc = dev_alloc(&s, new_cap * (ld_ ? ld_ : 4));
-    if (rc == OK) rc = dev_alloc(&inv, new_cap);
-    if (rc == OK) rc = dev_alloc(&fl, new_cap);
-    if (rc != OK) {
-        if (m) (void)hipFree(m);
-        if (s) (void)hipFree(s);
-        if (inv) (void)hipFree(inv);
-        if (fl) (void)hipFree(fl);
-        return rc;
-    }
-    const uint64_t n = ids_.size();
-    hipError_t ce = hipSuccess;
-    if (n) {
-        ce = hipMemcpyAsync(m, d_master_, n * dim_ * sizeof(double), hipMemcpyDeviceToDevice, mut_stream_);
-        if (ce == hipSuccess) ce = hipMemcpyAsync(s, d_slab_, n * ld_ * sizeof(float), hipMemcpyDeviceToDevice, mut_stream_);
-        if (ce == hipSuccess) ce = hipMemcpyAsync(inv, d_inv_norm_, n * sizeof(float), hipMemcpyDeviceToDevice, mut_stream_);
-        if (ce == hipSuccess) ce = hipMemcpyAsync(fl, d_flags_, n, hipMemcpyDeviceToDevice, mut_stream_);
-    }
-    const hipError_t se = hipStreamSynchronize(mut_stream_);
-    if (ce == hipSuccess) ce = se;
-    if (ce != hipSuccess) {  // the old buffers stay the index; the new ones are not leaked
-        (void)hipFree(m);
-        (void)hipFree(s);
-        (void)hipFree(inv);
-        (void)hipFree(fl);
-        set_last_error(std::string("growing the row store failed: ") + hipGetErrorString(ce));
-        return ERR_DEVICE;
-    }
-    if (d_master_) (void)hipFree(d_master_);
-    if (d_slab_) (void)hipFree(d_slab_);
-    if (d_inv_norm_) (void)hipFree(d_inv_norm_);
-    if (d_flags_) (void)hipFree(d_flags_);
-    d_master_ = m;
-    d_slab_ = s;
-    d_inv_norm_ = inv;
-    d_flags_ = fl;
-    cap_ = new_cap;
-    if (d_norm16_) {  // rebuilt on demand by the next large batch
+    // The bf16 copies of the slab are rebuilt on demand by the next large batch: they go first -- at tens of millions of
+    // rows they are tens of gigabytes the growth below can use.
+    if (d_norm16_) {
         if (d_slab16_) (void)hipFree(d_slab16_);
         if (d_slab16f_) (void)hipFree(d_slab16f_);
         (void)hipFree(d_sqnorm_);
@@ -272,7 +230,44 @@ int GpuFlatIndex::ensure_capacity(uint64_t rows)
         slab16_rows_ = 0;
         slab16f_rows_ = 0;
     }
-    return OK;
+    const uint64_t n = ids_.size();
+    // One array at a time: allocate the larger one, copy, free the old one.  The transient need is the index as it stands
+    // plus the LARGEST new array (the f64 master), not plus all four -- an index that was never reserve()d can grow to
+    // well past half of the card (growing all four at once failed at 34 M x 384 rows with 138 GiB free).  An array that
+    // has grown keeps its capacity if a later one fails: cap_ (the minimum) moves only when all four hold new_cap rows.
+    auto grow = [&](auto*& ptr, uint64_t& cap_arr, uint64_t new_cap, uint64_t per_row) -> int {
+        if (cap_arr >= new_cap) return OK;
+        using T = std::remove_reference_t<decltype(*ptr)>;
+        T* fresh = nullptr;
+        VL_TRY(dev_alloc(&fresh, new_cap * per_row));
+        hipError_t ce = hipSuccess;
+        if (n && ptr) ce = hipMemcpyAsync(fresh, ptr, n * per_row * sizeof(T), hipMemcpyDeviceToDevice, mut_stream_);
+        const hipError_t se = hipStreamSynchronize(mut_stream_);
+        if (ce == hipSuccess) ce = se;
+        if (ce != hipSuccess) {  // the old array stays the index; the new one is not leaked
+            (void)hipGetLastError();
+            (void)hipFree(fresh);
+            set_last_error(std::string("growing the row store failed: ") + hipGetErrorString(ce));
+            return ERR_DEVICE;
+        }
+        if (ptr) (void)hipFree(ptr);
+        ptr = fresh;
+        cap_arr = new_cap;
+        return OK;
+    };
+    auto attempt = [&](uint64_t new_cap) -> int {
+        VL_TRY(grow(d_master_, cap_master_, new_cap, dim_ ? dim_ : 1));
+        VL_TRY(grow(d_slab_, cap_slab_, new_cap, ld_ ? ld_ : 4));
+        VL_TRY(grow(d_inv_norm_, cap_inv_, new_cap, 1));
+        VL_TRY(grow(d_flags_, cap_flags_, new_cap, 1));
+        cap_ = std::min(std::min(cap_master_, cap_slab_), std::min(cap_inv_, cap_flags_));
+        return OK;
+    };
+    const uint64_t grown = cap_ < (1ull << 20) ? cap_ * 2 : cap_ + cap_ / 2;
+    const uint64_t geometric = std::max<uint64_t>({rows, grown, 1024});
+    int rc = attempt(geometric);
+    if (rc == ERR_OOM && rows < geometric) rc = attempt(rows);  // no room for the geometric step: exactly what was asked for
+    return rc;
 }
 
 // Rows [first, first+n) of d_master_ are in place: derive slab / inv_norm / flags / stats.

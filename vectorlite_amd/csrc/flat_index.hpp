@@ -220,7 +220,8 @@ private:
     mutable uint64_t slab16f_rows_ = 0;
     mutable std::mutex bf16_mu_;
     IngestStats* d_stats_ = nullptr;
-    uint64_t cap_ = 0;
+    uint64_t cap_ = 0;  // rows every array holds (the minimum of the four below)
+    uint64_t cap_master_ = 0, cap_slab_ = 0, cap_inv_ = 0, cap_flags_ = 0;
     hipStream_t mut_stream_ = nullptr;
     void* d_bounce_ = nullptr;  // delete compaction buffer
     size_t bounce_bytes_ = 0;
