@@ -10,6 +10,7 @@
 #include <chrono>
 
 #include <algorithm>
+#include <map>
 #include <type_traits>
 #include <cmath>
 #include <cstring>
@@ -103,6 +104,7 @@ Workspace::~Workspace()
 GpuFlatIndex::GpuFlatIndex(uint64_t dim, int device)
     : dim_(dim), ld_((uint32_t)((dim + 3) & ~3ull)), device_(device)
 {
+    ws_pool_ = attach_pool(device, dim);
 }
 
 namespace {
@@ -185,10 +187,52 @@ int GpuFlatIndex::create(uint64_t dim, int device, GpuFlatIndex** out)
     return OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// workspace pools, one per (device, dimension), shared by the handles (flat_index.hpp)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct PoolKey {
+    int device;
+    uint64_t dim;
+    bool operator<(const PoolKey& o) const { return device != o.device ? device < o.device : dim < o.dim; }
+};
+std::mutex g_pools_mu;
+// never destroyed: a pool that outlives main() (handles leaked by a host that exits without destroying them) must not
+// call into a HIP runtime that is already gone from a static destructor
+auto& g_pools = *new std::map<PoolKey, std::unique_ptr<WorkspacePool>>();
+}  // namespace
+
+WorkspacePool* GpuFlatIndex::attach_pool(int device, uint64_t dim)
+{
+    std::lock_guard<std::mutex> g(g_pools_mu);
+    auto& slot = g_pools[PoolKey{device, dim}];
+    if (!slot) slot.reset(new WorkspacePool());
+    slot->users += 1;
+    return slot.get();
+}
+
+void GpuFlatIndex::detach_pool(int device, uint64_t dim)
+{
+    std::unique_ptr<WorkspacePool> last;
+    {
+        std::lock_guard<std::mutex> g(g_pools_mu);
+        auto it = g_pools.find(PoolKey{device, dim});
+        if (it == g_pools.end()) return;
+        if (--it->second->users == 0) {
+            last = std::move(it->second);
+            g_pools.erase(it);
+        }
+    }
+    if (last) {
+        (void)hipSetDevice(device);
+        last->all.clear();  // ~Workspace frees its buffers
+    }
+}
+
 GpuFlatIndex::~GpuFlatIndex()
 {
     (void)hipSetDevice(device_);
-    ws_all_.clear();
+    if (ws_pool_) detach_pool(device_, dim_);
     if (mut_stream_) (void)hipStreamSynchronize(mut_stream_);
     void* dev[] = {d_master_, d_slab_, d_inv_norm_, d_flags_, d_stats_, d_bounce_, d_slab16_, d_sqnorm_, d_norm16_, d_slab16f_};
     for (void* p : dev)
@@ -480,26 +524,27 @@ int GpuFlatIndex::prepare_ws(Workspace* ws) const
 
 Workspace* GpuFlatIndex::acquire_ws() const
 {
+    WorkspacePool* pool = ws_pool_;
     {
-        std::lock_guard<std::mutex> g(ws_mu_);
-        if (!ws_free_.empty()) {
-            Workspace* w = ws_free_.back();
-            ws_free_.pop_back();
+        std::lock_guard<std::mutex> g(pool->mu);
+        if (!pool->free_.empty()) {
+            Workspace* w = pool->free_.back();
+            pool->free_.pop_back();
             return w;
         }
     }
     std::unique_ptr<Workspace> w(new Workspace());
     if (prepare_ws(w.get()) != OK) return nullptr;
     Workspace* raw = w.get();
-    std::lock_guard<std::mutex> g(ws_mu_);
-    ws_all_.push_back(std::move(w));
+    std::lock_guard<std::mutex> g(pool->mu);
+    pool->all.push_back(std::move(w));
     return raw;
 }
 
 void GpuFlatIndex::release_ws(Workspace* ws) const
 {
-    std::lock_guard<std::mutex> g(ws_mu_);
-    ws_free_.push_back(ws);
+    std::lock_guard<std::mutex> g(ws_pool_->mu);
+    ws_pool_->free_.push_back(ws);
 }
 
 void GpuFlatIndex::profile_enable(bool on) { profile_.store(on); }

@@ -89,6 +89,17 @@ struct Workspace {
     ~Workspace();
 };
 
+// Search scratch (streams, partial-list buffers, the batch filter's buffers: ~10 MB, 80+ MB once a large batch ran) is
+// shared by every handle of one (device, dimension): the reference keeps a HashMap of collections (src/client.rs:243-247),
+// and thousands of small handles each holding their own scratch held 14.6 MB apiece (tools/many_handles_probe.py).
+// Reference-counted: the pool of a (device, dimension) goes when its last handle does.
+struct WorkspacePool {
+    std::mutex mu;
+    std::vector<Workspace*> free_;
+    std::vector<std::unique_ptr<Workspace>> all;
+    size_t users = 0;
+};
+
 class GpuFlatIndex {
 public:
     struct CoalesceReq {  // one caller waiting in search_coalesced()
@@ -235,9 +246,9 @@ private:
     mutable bool id_counts_valid_ = true;
 
     // workspace pool
-    mutable std::mutex ws_mu_;
-    mutable std::vector<Workspace*> ws_free_;
-    mutable std::vector<std::unique_ptr<Workspace>> ws_all_;
+    static WorkspacePool* attach_pool(int device, uint64_t dim);
+    static void detach_pool(int device, uint64_t dim);
+    WorkspacePool* ws_pool_ = nullptr;
 
     mutable Coalescer<CoalesceReq> co_;
 
