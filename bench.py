@@ -478,10 +478,15 @@ def run_c3(V, torch, dist, args, dev, dev_index, rank, world, rehearse, k, cap_s
                      "traffic": None},
     }
     if dev_q is not None:
+        # the contract's `value` takes its inputs from HBM: the device-query form is the figure, the host form rides beside it
         dev_q["whole_call_frac_of_mfma_peak"] = round(flops_rank / (dev_q["ms_per_batch"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
         out["device_queries"] = dev_q
-        out["pcie_note"] = ("value / ms_per_batch take the 6.3 MB batch from HOST memory (pinned staging + PCIe copy inside the "
-                            "call: the PCIe-inclusive figure); device_queries is the same call with the batch resident in HBM")
+        out["host_queries_pcie_inclusive"] = {"value": out["value"], "unit": "queries/s", "ms_per_batch": out["ms_per_batch"],
+                                              "note": "the same batch handed over in host memory: pinned staging + a 6.3 MB PCIe copy inside the call"}
+        out["value"], out["ms_per_batch"] = dev_q["value"], dev_q["ms_per_batch"]
+        out["inputs"] = "the 1024 x 768 f64 query batch resident in each rank's HBM (vl_shard_search_batch_dev)"
+        out["roofline"]["whole_call"] = {"achieved": round(flops_rank / (dev_q["ms_per_batch"] * 1e-3) / 1e12, 1),
+                                         "frac": dev_q["whole_call_frac_of_mfma_peak"]}
     if prof and prof["calls"]:
         c = prof["calls"]
         out["exchange_ms_per_batch"] = {"local_search_host_clock": round(prof["local_ms"] / c, 3),
@@ -1029,13 +1034,28 @@ def run_rank(args) -> int:
         n_pass, ms5, _ = idx.profile_read()
         kern = ms5 / reps5 * 1e-3
         flops = 2.0 * nq5 * n * dim
+        # the contract's `value` takes its inputs from HBM: the same batch resident in device memory
+        # (vl_index_search_batch_dev: a kernel stages it); the host form above is the PCIe-inclusive figure beside it
+        dQ5 = torch.from_numpy(np.ascontiguousarray(Q5)).to(dev)
+        idx.search_batch_device(dQ5, k, metric)
+        torch.cuda.synchronize()
+        t5d = time.perf_counter()
+        for _ in range(reps5):
+            di, ds, dn5 = idx.search_batch_device(dQ5, k, metric)
+        w5d = (time.perf_counter() - t5d) / reps5
+        same5 = bool(np.array_equal(di, bi) and np.array_equal(ds, bs))
+        del dQ5
         pick = np.linspace(0, nq5 - 1, 16).astype(int)
         ok5 = 0
         for qi in pick:
             s_i, s_s = idx.search_arrays(Q5[qi], k, metric)
             ok5 += int(bi[qi].tolist() == s_i.tolist() and bs[qi].tolist() == s_s.tolist())
         other["c5"] = {"workload": f"batched flat {args.metric} search as a bf16 MFMA GEMM: Q={nq5}, N={n}, dim={dim}, k={k}, 1 GPU",
-                       "value": round(nq5 / w5, 1), "unit": "queries/s", "ms_per_batch": round(w5 * 1e3, 3),
+                       "value": round(nq5 / w5d, 1), "unit": "queries/s", "ms_per_batch": round(w5d * 1e3, 3),
+                       "inputs": "the 4096 x 384 f64 query batch resident in HBM (vl_index_search_batch_dev)",
+                       "host_queries_pcie_inclusive": {"value": round(nq5 / w5, 1), "unit": "queries/s", "ms_per_batch": round(w5 * 1e3, 3),
+                                                       "identical_to_device_queries": same5,
+                                                       "note": "the same batch handed over in host memory: pinned staging + a 12.6 MB PCIe copy inside the call"},
                        "launch_sequences_per_batch": n_pass // max(reps5, 1),
                        "rows_identical_to_single_search": f"{ok5}/16 sampled (ids and f64 scores)",
                        "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS,
@@ -1043,7 +1063,7 @@ def run_rank(args) -> int:
                                     "flops_per_batch": flops, "achieved": round(flops / kern / 1e12, 1) if kern > 0 else None,
                                     "frac": round(flops / kern / 1e12 / MFMA_PEAK_TFLOPS, 4) if kern > 0 else None,
                                     "filter_kernels_ms_per_batch": round(kern * 1e3, 3),
-                                    "whole_call": {"achieved": round(flops / w5 / 1e12, 1), "frac": round(flops / w5 / 1e12 / MFMA_PEAK_TFLOPS, 4)},
+                                    "whole_call": {"achieved": round(flops / w5d / 1e12, 1), "frac": round(flops / w5d / 1e12 / MFMA_PEAK_TFLOPS, 4)},
                                     "traffic": None}}
 
     def c3_block():

@@ -63,12 +63,16 @@ def test_bench_child_process_prints_the_whole_contract_line(steps, warmup):
     assert oc["c2"]["roofline"]["bound"] == "hbm" and 0 < oc["c2"]["roofline"]["frac"] < 1 and oc["c2"]["fast_vs_exact"].startswith("4/4")
     assert oc["c5"]["roofline"]["bound"] == "mfma" and oc["c5"]["roofline"]["frac"] > 0
     assert oc["c5"]["rows_identical_to_single_search"].startswith("16/16")
+    # `value` takes its inputs from HBM (the contract); the host form -- staging + PCIe inside the call -- rides beside it
+    assert oc["c5"]["host_queries_pcie_inclusive"]["identical_to_device_queries"] is True
+    assert oc["c5"]["host_queries_pcie_inclusive"]["ms_per_batch"] > 0 and oc["c5"]["ms_per_batch"] > 0
     c3 = oc["c3_shard"]
     assert c3["n_gpus"] == 1 and c3["rows_per_rank"] == 20000 and c3["roofline"]["bound"] == "mfma" and c3["roofline"]["frac"] > 0
     assert c3["own_rows_match_single_search"] == "4/4" and c3["transport"].startswith("RCCL")
     assert set(c3["exchange_ms_per_batch"]) >= {"ncclAllGather", "merge_kernel_and_d2h", "local_search_host_clock"}
     # the same batch taken from device memory (vl_shard_search_batch_dev): timed beside the host form, identical answer
     assert c3["device_queries"]["identical_to_host_queries"] is True and c3["device_queries"]["ms_per_batch"] > 0
+    assert c3["ms_per_batch"] == c3["device_queries"]["ms_per_batch"] and c3["host_queries_pcie_inclusive"]["ms_per_batch"] > 0
     c4 = oc["c4_hnsw"]
     assert c4["parity"].startswith("unpinned") and set(c4["data"]) == {"latent16", "iid_gaussian"}
     for dist_name in ("latent16", "iid_gaussian"):
