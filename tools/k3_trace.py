@@ -2,7 +2,7 @@ import sys, os, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, vectorlite_amd as V
 rng = np.random.default_rng(1)
-n, dim = 50_000, 64
+n, dim = 50_000, int(sys.argv[1]) if len(sys.argv) > 1 else 64
 rows = rng.standard_normal((n, dim)); idx = V.FlatIndex(dim); idx.add_rows(np.arange(n, dtype=np.uint64), rows)
 Q = rng.standard_normal((800, dim))
 idx.search_batch(Q[:64], 10, 2)
