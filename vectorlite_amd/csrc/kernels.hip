@@ -1427,7 +1427,8 @@ hipError_t launch_scan(hipStream_t s, int metric, const float* slab, const float
 }
 
 // Batch shapes: one (G, VPL) per supported row length, QB = 8 queries per pass.
-#define VL_BATCH_SHAPES(X) X(8, 4) X(8, 8) X(8, 12) X(8, 16) X(16, 12) X(16, 16) X(16, 24)
+// (lanes per row, 16-byte chunks per lane): row strides 32, 64, 96, 128, 192, 256, 320, 384, 512, 640, 768, 1024, 1536 floats
+#define VL_BATCH_SHAPES(X) X(8, 1) X(8, 2) X(8, 3) X(8, 4) X(8, 6) X(8, 8) X(8, 10) X(8, 12) X(8, 16) X(16, 10) X(16, 12) X(16, 16) X(16, 24)
 
 bool scan_batch_supported(uint32_t ld)
 {
