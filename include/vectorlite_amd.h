@@ -161,7 +161,8 @@ int vl_index_search(const vl_index *h, const double *query, uint64_t q_len, uint
 
 /* vl_index_search with an explicit output capacity: writes min(k, len, out_capacity) results -- the first
  * out_capacity entries of what vl_index_search would write (`truncate(k)`, src/index/flat.rs:117, applied once
- * more).  A caller that sized its buffers from an earlier vl_index_len() cannot be overrun by a concurrent add():
+ * more).  On an HNSW handle the walk still runs with the caller's k (its beam is ef = min(k, len),
+ * src/index/hnsw.rs:437): only the copy-out is capped, so the entries ARE that prefix.  A caller that sized its buffers from an earlier vl_index_len() cannot be overrun by a concurrent add():
  * the bound is the caller's own number, not the index's length at search time.  The Rust / Python / C bindings of
  * this repository all call this form. */
 int vl_index_search_cap(const vl_index *h, const double *query, uint64_t q_len, uint64_t k, int metric,
@@ -174,7 +175,8 @@ int vl_index_search_batch(const vl_index *h, const double *queries, uint64_t nq,
                           int metric, uint64_t *out_ids, double *out_scores, uint64_t *out_n);
 
 /* The batch form with an explicit row capacity: out_ids / out_scores are [nq, out_stride]; row i receives
- * min(k, len, out_stride) entries, out_n[i] says how many. */
+ * min(k, len, out_stride) entries, out_n[i] says how many (HNSW: the first out_stride entries of the walk with the
+ * caller's k, as above). */
 int vl_index_search_batch_cap(const vl_index *h, const double *queries, uint64_t nq, uint64_t q_len, uint64_t k,
                               int metric, uint64_t out_stride, uint64_t *out_ids, double *out_scores, uint64_t *out_n);
 
@@ -189,12 +191,14 @@ int vl_index_metric(const vl_index *h, int *out_metric);
 
 /* HNSW only, own extension (the reference has no ef knob): nq walks with beam width
  * max(ef, min(k, len)); outputs as vl_index_search_batch.  ef = 0 is what vl_index_search does: the reference's
- * ef = min(k, len) (src/index/hnsw.rs:437,454), raised to the handle's beam floor only if the caller set one (below). */
+ * ef = min(k, len) (src/index/hnsw.rs:437,454), raised to the handle's beam floor only if the caller set one (below).
+ * The walk kernel holds beams of up to 512 entries; ef > 512 is VL_ERR_INVALID_ARG (never silently narrowed), and
+ * min(k, len) > 512 is answered by the exact scan of the row store. */
 int vl_index_search_ef(const vl_index *h, const double *queries, uint64_t nq, uint64_t q_len, uint64_t k,
                        uint32_t ef, int metric, uint64_t *out_ids, double *out_scores, uint64_t *out_n);
 
 /* HNSW handle: OPT-IN beam floor of searches that name no ef.  DEFAULT 0 = the reference's rule: the walk keeps
- * ef = min(k, len) entries (src/index/hnsw.rs:437) -- 10 for k = 10.  With min_beam > 0 (at most 128) the walk keeps at
+ * ef = min(k, len) entries (src/index/hnsw.rs:437) -- 10 for k = 10.  With min_beam > 0 (at most 512) the walk keeps at
  * least that many entries and returns the best min(k, len) of them: the same number of results, recall@10 0.96
  * instead of 0.78 at N = 1 M on embedding-like data with min_beam = 32.  That is a DEVIATION from the reference's walk
  * width, which is why it is off unless asked for (env VL_HNSW_MIN_BEAM sets it for handles created afterwards). */
@@ -377,7 +381,13 @@ int vl_index_set_single_filter(vl_index *h, int mode);
  * max_batch >= 2: callers that arrive while a scan is in flight are answered together by the next
  * slab pass / graph-walk launch (at most max_batch per pass; vl_index_search_batch's kernels); each caller still gets
  * exactly the result and status a lone vl_index_search returns.  window_us > 0 additionally lets a
- * lone caller wait that long for company.  max_batch 0/1 = off (default).
+ * lone caller wait that long for company.  max_batch 0/1 = off.
+ * DEFAULT (round 4): ON with max_batch 256 and window 0 for every handle -- the reference's many-readers usage
+ * (16 threads on one 10 M x 384 index: 456 QPS / 35 ms per query with separate scans, 5.3 k QPS / 3.0 ms coalesced,
+ * identical answers); a lone caller finds no pass in flight, leads a pass of one and runs exactly the single-search
+ * path (no wait, no batch kernels).  The first pass that answers two or more queries on an index of >= 8192 rows
+ * builds the batch filter's bf16 copy of the rows (+2 bytes per value).  VL_COALESCE=0 in the
+ * environment makes handles created afterwards start with it off; vl_index_set_coalescing(h, 0, 0) turns it off.
  * vl_index_coalesce_stats: passes run and queries answered by them since creation. */
 int vl_index_set_coalescing(vl_index *h, int max_batch, int window_us);
 int vl_index_coalesce_stats(const vl_index *h, uint64_t *batches, uint64_t *queries);

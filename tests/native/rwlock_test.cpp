@@ -3,6 +3,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <ctime>
 #include <mutex>
 #include <shared_mutex>
 #include <thread>
@@ -58,6 +59,32 @@ int main()
     if (max_readers.load() < 2) {
         std::printf("FAILED: readers never ran side by side\n");
         return 1;
+    }
+    // Readers that stand back behind a waiting writer must SLEEP, not spin (advisor, round 3): a writer waits 300 ms behind
+    // one long reader while 6 more readers arrive; together they may use a few ms of CPU, not 6 x 300 ms.
+    {
+        vl::RwLock mu2;
+        std::atomic<bool> long_reader_in{false};
+        std::thread long_reader([&]() {
+            std::shared_lock<vl::RwLock> lk(mu2);
+            long_reader_in.store(true);
+            std::this_thread::sleep_for(std::chrono::milliseconds(300));
+        });
+        while (!long_reader_in.load()) std::this_thread::yield();
+        std::thread writer([&]() { std::unique_lock<vl::RwLock> lk(mu2); });
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));  // the writer is queued by now
+        const std::clock_t c0 = std::clock();                       // process CPU time, all threads
+        std::vector<std::thread> late;
+        for (int t = 0; t < 6; ++t) late.emplace_back([&]() { std::shared_lock<vl::RwLock> lk(mu2); });
+        for (auto& x : late) x.join();
+        const double cpu_ms = 1000.0 * (double)(std::clock() - c0) / CLOCKS_PER_SEC;
+        writer.join();
+        long_reader.join();
+        std::printf("6 readers behind a queued writer for ~280 ms used %.1f ms of CPU\n", cpu_ms);
+        if (cpu_ms > 200.0) {
+            std::printf("FAILED: waiting readers burn CPU (they should block)\n");
+            return 1;
+        }
     }
     if (total_ms > 2000.0) {  // 200 x (one reader's 0.2 ms to drain + the write): a starved writer takes far longer
         std::printf("FAILED: the writer was starved\n");

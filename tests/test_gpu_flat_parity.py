@@ -582,6 +582,57 @@ def test_coalesced_concurrent_searches_match_lone_searches(V, O):
     assert gpu.coalesce_stats() == (batches, queries)
 
 
+def test_coalescing_is_on_by_default_and_a_lone_caller_takes_the_single_search_path(V, O, monkeypatch):
+    """Round 4: handles start with coalescing on (max 256, window 0) -- the reference's many-readers usage
+    (src/client.rs:398, src/server.rs:269).  A lone caller leads a pass of one = the plain single search (fast path, no
+    batch kernels); concurrent callers share passes and get the lone answers; VL_COALESCE=0 starts handles with it off."""
+    import threading
+    rng = np.random.default_rng(404)
+    n, dim, k = 40000, 96, 10
+    rows = unit_rows(rng, n, dim)
+    ids = permuted_ids(n)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(ids, rows, validate=False)
+    ref = O.FlatOracle(dim, ids, rows)
+    Q = unit_rows(rng, 64, dim)
+    assert gpu.coalesce_stats() == (0, 0)
+    for i in range(4):
+        gi, gs = gpu.search_arrays(Q[i], k, i)
+        assert V.last_path() == V.PATH_FAST
+        ri, rs = ref.search(Q[i], k, i)
+        assert gi.tolist() == ri.tolist() and gs.tolist() == rs.tolist()
+    assert gpu.coalesce_stats() == (4, 4)          # four passes of one query each: nobody waited for anybody
+    want = [ref.search(Q[i], k, 0) for i in range(64)]
+    errors = []
+    bar = threading.Barrier(8)
+
+    def worker(t):
+        try:
+            bar.wait()
+            for rep in range(3):
+                for i in range(t, 64, 8):
+                    gi, gs = gpu.search_arrays(Q[i], k, 0)
+                    if gi.tolist() != want[i][0].tolist() or gs.tolist() != want[i][1].tolist():
+                        errors.append((t, i))
+        except Exception as e:  # pragma: no cover
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert errors == []
+    batches, queries = gpu.coalesce_stats()
+    assert queries == 4 + 3 * 64 and batches < queries   # passes were shared without anybody asking for it
+    c = gpu.clone()
+    c.search_arrays(Q[0], k, 0)
+    assert c.coalesce_stats() == (1, 1)            # a clone starts the same way
+    monkeypatch.setenv("VL_COALESCE", "0")
+    off = V.FlatIndex(dim)
+    off.add_rows(ids[:1000], rows[:1000], validate=False)
+    off.search_arrays(Q[0], k, 0)
+    assert off.coalesce_stats() == (0, 0)
+
+
 def test_large_index_properties(V):
     """N = 2M x 128 (too big for the oracle in a test): fast path == exact path bit for bit,
     sortedness, idempotence, self-query returns the row itself with score 1, delete removes it."""

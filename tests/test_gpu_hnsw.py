@@ -269,7 +269,9 @@ def test_coalesced_concurrent_hnsw_searches_match_lone_searches(V):
     nq = 128
     Q = z[rng.integers(0, n, nq)] + 0.01 * rng.standard_normal((nq, dim))
     ks = [10 if i % 4 else 5 for i in range(nq)]
+    idx.set_coalescing(0)                      # the lone answers come from uncoalesced searches ...
     want = [[(r.id, r.score) for r in idx.search(Q[i], ks[i], V.SimilarityMetric.Cosine)] for i in range(nq)]
+    assert idx.coalesce_stats() == (0, 0)
     idx.set_coalescing(256, 200)
     errors = []
     bar = threading.Barrier(16)
@@ -305,6 +307,7 @@ def test_concurrent_hnsw_searches_without_coalescing_borrow_separate_scratch(V):
     n, dim = 30000, 64
     z = rng.standard_normal((n, 10)) @ rng.standard_normal((10, dim))
     idx = V.HNSWIndex(dim, V.SimilarityMetric.Euclidean)
+    idx.set_coalescing(0)                      # coalescing is the default since round 4: this test is about the launches that overlap without it
     idx.add_rows(np.arange(n, dtype=np.uint64) + 7, z)
     nq = 192
     Q = z[rng.integers(0, n, nq)] + 0.01 * rng.standard_normal((nq, dim))
@@ -371,7 +374,7 @@ def test_large_embedding_dimensions(V, O, dim):
 
 
 def test_k_above_the_beam_limit_is_answered_exactly(V, O):
-    """ef = min(k, len) > 128 does not fit the walk kernel's beam: the row store's exact scan answers, in
+    """ef = min(k, len) > 512 does not fit the walk kernel's beam: the row store's exact scan answers, in
     Metric::distance order, with the walk's post-processing (tombstones dropped, scores converted, stable sort)."""
     rng = np.random.default_rng(77)
     n, dim = 1500, 24
@@ -383,7 +386,7 @@ def test_k_above_the_beam_limit_is_answered_exactly(V, O):
     for dead in (3, 77, 600):
         idx.delete(int(ids[dead]))
     q = z[10] + 0.05
-    for k in (129, 400, 5000):
+    for k in (513, 900, 5000):
         res = idx.search(q, k, m)
         live = [i for i in range(n) if i not in (3, 77, 600)]
         d = {i: O.hnsw_distance(1, q, z[i]) for i in live}
@@ -452,3 +455,88 @@ def test_huge_k_on_a_small_hnsw_index_returns_len_results(V):
         assert ids.tolist() == want
     # the Python wrapper clamps k to its buffers the same way
     assert [r.id for r in idx.search(rows[3], 2 ** 62, V.SimilarityMetric.Euclidean)] == want
+
+
+def test_beams_up_to_512_walk_and_wider_requests_are_refused_not_narrowed(V, O):
+    """Round 4: the walk holds beams of up to 512 entries (1 / 2 / 4 / 8 sorted-list entries per lane), so the crate's
+    construction default (ef_construction = 400, SURVEY 9.5) and searches with 128 < min(k, len) <= 512 run on the graph;
+    an explicit ef beyond the ceiling is VL_ERR_INVALID_ARG -- rounds 1-3 silently walked with 128."""
+    rng = np.random.default_rng(4242)
+    n, dim, k = 12000, 32, 10
+    rows, A = latent_rows(rng, n, dim, 8)
+    ids = np.arange(n, dtype=np.uint64) + 3
+    m = V.SimilarityMetric.Cosine
+    Q, _ = latent_rows(rng, 48, dim, 8, A)
+    flat = V.FlatIndex(dim)
+    flat.add_rows(ids, rows, validate=False)
+    truth = [set(flat.search_arrays(Q[i], k, 0)[0].tolist()) for i in range(len(Q))]
+
+    def recall(bi):
+        return float(np.mean([len(truth[i] & set(bi[i, :k].tolist())) / k for i in range(len(Q))]))
+
+    rec = {}
+    for efc in (64, 200, 400, 512):           # the four list shapes of the build kernel
+        idx = V.HNSWIndex(dim, m, ef_construction=efc)
+        idx.add_rows(ids, rows)
+        assert len(idx) == n
+        for ef in (10, 64, 128, 256, 512):    # ... and of the walk kernel
+            bi, bs, bn = idx.search_batch(Q, k, m, ef=ef)
+            assert bn.tolist() == [k] * len(Q)
+            assert all(bs[q, j - 1] >= bs[q, j] for q in range(len(Q)) for j in range(1, k))
+            rec[(efc, ef)] = recall(bi)
+        # every returned score is the reference's conversion of the exact u64 callback value, whatever the beam
+        gi, gs = idx.search_arrays(Q[0], k, m, ef=400)
+        assert gs.tolist() == [O.hnsw_score(O.hnsw_distance(0, Q[0], rows[int(i) - 3]), 0) for i in gi]
+        # k itself above 128: a walk with ef = min(k, len) = 300 now (it used to be the exact scan)
+        e0 = idx.walk_stats()[1]
+        ri, rs = idx.search_arrays(Q[1], 300, m)
+        assert len(ri) == 300 and len(set(ri.tolist())) == 300 and all(rs[j - 1] >= rs[j] for j in range(1, 300))
+        assert idx.walk_stats()[1] - e0 < n      # a walk, not a scan of every row
+        want300 = set(flat.search_arrays(Q[1], 300, 0)[0].tolist())
+        assert len(want300 & set(ri.tolist())) >= 270
+        with pytest.raises(V.VectorLiteError, match="exceeds the walk's beam ceiling"):
+            idx.search_batch(Q, k, m, ef=513)
+    print("recall@10 by (ef_construction, ef):", {k_: round(v, 3) for k_, v in rec.items()})
+    for efc in (64, 200, 400, 512):
+        assert rec[(efc, 512)] >= 0.99 and rec[(efc, 512)] >= rec[(efc, 64)] - 1e-9 >= rec[(efc, 10)] - 0.05
+    with pytest.raises(V.VectorLiteError, match="ef_construction"):
+        V.HNSWIndex(dim, m, ef_construction=513)
+
+
+def test_search_cap_on_hnsw_keeps_the_callers_beam(V):
+    """Advisor, round 3: vl_index_search_cap narrowed the WALK to the capacity (ef = min(k, len) follows k), so its output
+    was not the prefix the header promises.  The walk now keeps the caller's k; only the copy-out is capped."""
+    import ctypes as C
+    rng = np.random.default_rng(9)
+    n, dim = 8000, 24
+    rows, A = latent_rows(rng, n, dim, 6)
+    m = V.SimilarityMetric.Cosine
+    idx = V.HNSWIndex(dim, m)
+    idx.add_rows(np.arange(n, dtype=np.uint64), rows)
+    Q, _ = latent_rows(rng, 6, dim, 6, A)
+    L = idx._L
+    pd, pu = C.POINTER(C.c_double), C.POINTER(C.c_uint64)
+    for qi in range(6):
+        q = np.ascontiguousarray(Q[qi])
+        full_i, full_s = idx.search_arrays(q, 64, m)
+        ids = np.zeros(5, np.uint64)
+        sc = np.zeros(5, np.float64)
+        cnt = C.c_uint64(0)
+        e0 = idx.walk_stats()[1]
+        rc = L.vl_index_search_cap(idx._h, q.ctypes.data_as(pd), dim, 64, int(m), 5, ids.ctypes.data_as(pu), sc.ctypes.data_as(pd), C.byref(cnt))
+        assert rc == 0 and cnt.value == 5
+        assert ids.tolist() == full_i[:5].tolist() and sc.tolist() == full_s[:5].tolist()
+        e_cap = idx.walk_stats()[1] - e0
+        e0 = idx.walk_stats()[1]
+        idx.search_arrays(q, 64, m)
+        assert e_cap == idx.walk_stats()[1] - e0     # the same walk (deterministic): same number of distance evaluations
+    # the batch form: rows 7 apart, 7 entries each, from the walk with k = 64
+    Qc = np.ascontiguousarray(Q)
+    ids = np.zeros((6, 7), np.uint64)
+    sc = np.zeros((6, 7), np.float64)
+    cn = np.zeros(6, np.uint64)
+    rc = L.vl_index_search_batch_cap(idx._h, Qc.ctypes.data_as(pd), 6, dim, 64, int(m), 7, ids.ctypes.data_as(pu), sc.ctypes.data_as(pd),
+                                     cn.ctypes.data_as(pu))
+    assert rc == 0 and cn.tolist() == [7] * 6
+    bi, bs, bn = idx.search_batch(Qc, 64, m)
+    assert ids.tolist() == bi[:, :7].tolist() and sc.tolist() == bs[:, :7].tolist()

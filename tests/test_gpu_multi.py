@@ -294,8 +294,7 @@ def test_concurrent_callers_of_single_and_batch_searches_on_a_three_part_handle(
         except Exception as e:  # noqa: BLE001
             errors.append(repr(e))
     for coalesce in (False, True):   # second round: every part coalesces its concurrent single searches into shared slab passes
-        if coalesce:
-            m.set_coalescing(32, 100)
+        m.set_coalescing(32, 100) if coalesce else m.set_coalescing(0)   # (on by default since round 4: the first round turns it off)
         th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
         for t in th:
             t.start()
@@ -303,3 +302,64 @@ def test_concurrent_callers_of_single_and_batch_searches_on_a_three_part_handle(
             t.join()
         assert errors == [], (coalesce, errors)
     assert len(m) == n
+
+
+@pytest.mark.parametrize("mode", ["replicas", "row_shards"])
+def test_a_part_that_fails_a_bulk_add_leaves_every_part_as_it_was(mode, monkeypatch):
+    """Advisor, round 3: a fan-out that failed on ONE part used to leave the replicas diverged for good (and a sharded index
+    holding a non-prefix subset of the batch).  Now every part makes room first and, if a part fails anyway, every part
+    forgets the rows of that call: the handle answers exactly as before the call, and the retry goes through."""
+    import vectorlite_amd as V
+    from oracle import oracle as O
+    rng = np.random.default_rng(77)
+    dim, n0, n1 = 32, 900, 600
+    rows = _unit(rng, n0 + n1, dim)
+    ids = np.arange(n0 + n1, dtype=np.uint64) + np.uint64(1000)
+    m = V.MultiFlatIndex(dim, [0, 0, 0], mode)
+    ref = O.FlatOracle(dim)
+    m.add_rows(ids[:n0], rows[:n0], validate=True)
+    ref.extend(ids[:n0], rows[:n0])
+    Q = _unit(rng, 12, dim)
+    before = [m.search_arrays(Q[i], 10, i % 4) for i in range(12)]
+    for bad_part in (0, 1, 2):
+        monkeypatch.setenv("VL_MULTI_INJECT_ADD_FAIL", str(bad_part))
+        with pytest.raises(V.VectorLiteError, match="injected add failure"):
+            m.add_rows(ids[n0:], rows[n0:], validate=True)
+        monkeypatch.delenv("VL_MULTI_INJECT_ADD_FAIL")
+        assert len(m) == n0
+        parts = m.parts()
+        assert (parts["rows"] == [n0] * 3) if mode == "replicas" else (sum(parts["rows"]) == n0)
+        for rep in range(3):                  # replicas: every replica is asked in turn (round robin) -- all say the same
+            for i in range(12):
+                _same(m.search_arrays(Q[i], 10, i % 4), before[i])
+        assert m.get_vector(int(ids[n0 + 5])) is None
+    # the retry is a plain add: no "already exists" from parts that had kept their share
+    m.add_rows(ids[n0:], rows[n0:], validate=True)
+    ref.extend(ids[n0:], rows[n0:])
+    assert len(m) == n0 + n1
+    for rep in range(3):
+        for i in range(12):
+            _same(m.search_arrays(Q[i], 10, i % 4), ref.search(Q[i], 10, i % 4))
+    bi, bs, bn = m.search_batch(Q, 7, 1)
+    for i in range(12):
+        wi, ws = ref.search(Q[i], 7, 1)
+        assert bi[i, :bn[i]].tolist() == wi.tolist() and bs[i, :bn[i]].tolist() == ws.tolist()
+
+
+def test_a_delete_that_fails_on_one_part_retires_the_handle(monkeypatch):
+    """A compaction that died half way cannot be rolled back: the parts disagree, so the handle refuses every later call
+    instead of serving answers that depend on which replica is asked."""
+    import vectorlite_amd as V
+    rng = np.random.default_rng(78)
+    dim, n = 16, 300
+    rows = _unit(rng, n, dim)
+    m = V.MultiFlatIndex(dim, [0, 0], "replicas")
+    m.add_rows(np.arange(n, dtype=np.uint64), rows, validate=False)
+    monkeypatch.setenv("VL_MULTI_INJECT_DELETE_FAIL", "1")
+    with pytest.raises(V.VectorLiteError, match="injected delete failure"):
+        m.delete(7)
+    monkeypatch.delenv("VL_MULTI_INJECT_DELETE_FAIL")
+    for call in (lambda: m.search_arrays(rows[0], 3, 0), lambda: m.search_batch(rows[:4], 3, 0),
+                 lambda: m.add(V.Vector(5000, rows[1])), lambda: m.delete(8)):
+        with pytest.raises(V.VectorLiteError, match="no longer answers"):
+            call()

@@ -292,26 +292,54 @@ int vl_index_search(const vl_index* h, const double* query, uint64_t q_len, uint
 int vl_index_search_cap(const vl_index* h, const double* query, uint64_t q_len, uint64_t k, int metric,
                         uint64_t out_capacity, uint64_t* out_ids, double* out_scores, uint64_t* out_n)
 {
-    // results for a smaller k are a prefix of those for a larger k (one total order: score desc, insertion order):
-    // truncating k to the capacity IS writing the first `out_capacity` entries of the k results
+    // Flat: results for a smaller k are a prefix of those for a larger k (one total order: score desc, insertion
+    // order), so truncating k to the capacity IS writing the first `out_capacity` entries of the k results.
+    // HNSW: k also sets the walk's beam (ef = min(k, len), src/index/hnsw.rs:437), so the walk keeps the caller's k and
+    // only the copy-out is capped.
+    if (h && h->hnsw && k > out_capacity)
+        return guarded([&]() -> int {
+            if (!out_n) return VL_ERR_INVALID_ARG;
+            if (out_capacity == 0) {  // nothing may be written: the walk's errors are still the caller's to see
+                uint64_t id1 = 0;
+                double sc1 = 0.0;
+                const int rc = h->hnsw->search(query, q_len, k, metric, 0, &id1, &sc1, out_n, 1);
+                *out_n = 0;
+                return rc;
+            }
+            return h->hnsw->search(query, q_len, k, metric, 0, out_ids, out_scores, out_n, out_capacity);
+        });
     return vl_index_search(h, query, q_len, k < out_capacity ? k : out_capacity, metric, out_ids, out_scores, out_n);
 }
 
 int vl_index_search_batch_cap(const vl_index* h, const double* queries, uint64_t nq, uint64_t q_len, uint64_t k,
                               int metric, uint64_t out_stride, uint64_t* out_ids, double* out_scores, uint64_t* out_n)
 {
+    if (h && h->hnsw)  // the walk keeps the caller's k (its beam is ef = min(k, len)); rows out_stride apart, capped at out_stride
+        return guarded([&]() -> int {
+            if (!out_n && nq) return VL_ERR_INVALID_ARG;
+            if (nq == 0) return VL_OK;
+            if (out_stride == 0) {
+                for (uint64_t q = 0; q < nq; ++q) out_n[q] = 0;
+                return VL_OK;
+            }
+            return h->hnsw->search_batch(queries, nq, q_len, k, metric, 0, out_ids, out_scores, out_n, out_stride);
+        });
     if (k >= out_stride)  // rows are then exactly out_stride apart, which is the plain call's layout for k = out_stride
         return vl_index_search_batch(h, queries, nq, q_len, out_stride, metric, out_ids, out_scores, out_n);
     return guarded([&]() -> int {
         if (!h || (!out_n && nq)) return VL_ERR_INVALID_ARG;
         if (nq == 0) return VL_OK;
-        // k < out_stride: answer into [nq, kk] scratch (kk = min(k, len): nothing larger is ever written) and spread the rows
-        const uint64_t len = vl_index_len(h);
-        const uint64_t kk = k < len ? k : len;
+        // k < out_stride: answer into [nq, kk] scratch and spread the rows.  kk = k whenever that scratch is of a sane size:
+        // the library bounds what it writes by min(k, len) under its own lock, so no length snapshot (which a concurrent
+        // add could outdate) is involved; an absurd k falls back to min(k, len now).
+        uint64_t kk = k;
+        if (k > (1ull << 26) / nq) {
+            const uint64_t len = vl_index_len(h);
+            kk = k < len ? k : len;
+        }
         std::vector<uint64_t> ids(nq * kk);
         std::vector<double> scores(nq * kk);
-        const int rc = h->hnsw ? h->hnsw->search_batch(queries, nq, q_len, kk, metric, 0, ids.data(), scores.data(), out_n)
-                               : on_flat(h, [&](auto* f) { return f->search_batch(queries, nq, q_len, kk, metric, nullptr, ids.data(), scores.data(), out_n); });
+        const int rc = on_flat(h, [&](auto* f) { return f->search_batch(queries, nq, q_len, kk, metric, nullptr, ids.data(), scores.data(), out_n); });
         if (rc != VL_OK) return rc;
         for (uint64_t q = 0; q < nq; ++q) {
             const uint64_t m = out_n[q] < kk ? out_n[q] : kk;

@@ -183,6 +183,12 @@ int GpuFlatIndex::create(uint64_t dim, int device, GpuFlatIndex** out)
     if (const char* sf = getenv("VL_SINGLE_FILTER")) {
         if (std::strcmp(sf, "bf16") == 0) idx->set_single_filter(1);
     }
+    // Concurrent single searches share slab passes by default (the reference's many-readers model, src/client.rs:398):
+    // window 0, so a lone caller leads a pass of one = the plain single-search path.  VL_COALESCE=0 starts handles with it off.
+    {
+        const char* ce = getenv("VL_COALESCE");
+        if (!(ce && ce[0] == '0')) idx->set_coalescing(COALESCE_DEFAULT_BATCH, 0);
+    }
     *out = idx.release();
     return OK;
 }
@@ -251,6 +257,19 @@ int GpuFlatIndex::reserve(uint64_t n_rows)
     std::unique_lock<RwLock> lk(mu_);
     VL_HIP(hipSetDevice(device_));
     return ensure_capacity(n_rows);
+}
+
+void GpuFlatIndex::truncate(uint64_t n_rows)
+{
+    std::unique_lock<RwLock> lk(mu_);
+    if (n_rows >= ids_.size()) return;
+    for (uint64_t p = n_rows; p < row_flags_.size(); ++p)
+        if (row_flags_[p] & ROW_OUT_OF_DOMAIN) --n_out_of_domain_;
+    ids_.resize(n_rows);
+    row_flags_.resize(n_rows);
+    id_counts_valid_ = false;  // rebuilt on demand from ids_
+    if (slab16_rows_ > n_rows) slab16_rows_ = n_rows;
+    if (slab16f_rows_ > n_rows) slab16f_rows_ = n_rows;
 }
 
 int GpuFlatIndex::ensure_capacity(uint64_t rows)

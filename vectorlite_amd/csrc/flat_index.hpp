@@ -38,6 +38,8 @@ enum Status : int {
     ERR_INVALID_ARG = 8,
 };
 
+constexpr int COALESCE_DEFAULT_BATCH = 256;  // concurrent callers one pass answers at most, by default (window 0)
+
 enum Path : int { PATH_NONE = 0, PATH_FAST = 1, PATH_EXACT_SELECT = 2, PATH_EXACT_SORT = 3 };
 
 // thread-local diagnostics (vl_last_error & friends)
@@ -151,6 +153,9 @@ public:
 
     int clone(GpuFlatIndex** out) const;
     int reserve(uint64_t n_rows);
+    // forget the rows at positions >= n_rows (host bookkeeping only, cannot fail): how a multi-GPU handle takes back the
+    // part of a bulk add that another part could not complete
+    void truncate(uint64_t n_rows);
     int export_rows(uint64_t* out_ids, double* out_values) const;
     int hnsw_distances(const double* query, uint64_t q_len, int metric, const uint64_t* positions, uint64_t m,
                        uint64_t* out) const;
@@ -171,7 +176,8 @@ public:
         bf16_fails_.store(0);
     }
     // Group concurrent single-query search() calls into shared slab passes (coalescer.hpp, search_coalesced()).
-    // max_batch <= 1 turns it off (default).  window_us: how long a lone caller waits for company.
+    // max_batch <= 1 turns it off.  window_us: how long a lone caller waits for company.  create() turns it on with
+    // (COALESCE_DEFAULT_BATCH, 0) unless VL_COALESCE=0.
     void set_coalescing(int max_batch, int window_us) { co_.configure(max_batch, window_us, (int)MFMA_MAX_BATCH); }
     void coalesce_stats(uint64_t* batches, uint64_t* queries) const { co_.stats(batches, queries); }
     void profile_enable(bool on);

@@ -56,6 +56,7 @@ struct BeamList {
         const int lane = lane_id();
 #pragma unroll
         for (int s = S - 1; s >= 0; --s) {  // top slot first: it reads the slot below before that moves
+            if ((s + 1) * 64 <= idx) break;  // wave-uniform: this slot and the ones below it hold entries in front of idx
             const int j = s * 64 + lane;
             unsigned long long pd = wave_shr1(d[s]);
             uint32_t pv = wave_shr1(v[s]);
@@ -82,13 +83,15 @@ struct BeamList {
     }
     __device__ __forceinline__ void get(int idx, unsigned long long& dist, uint32_t& node) const
     {
-        if (S > 1 && idx >= 64) {
-            dist = read_lane(d[S - 1], idx - 64);
-            node = read_lane(v[S - 1], idx - 64);
-        } else {
-            dist = read_lane(d[0], idx);
-            node = read_lane(v[0], idx);
-        }
+        const int si = idx >> 6, l = idx & 63;  // idx is wave-uniform
+        dist = read_lane(d[0], l);
+        node = read_lane(v[0], l);
+#pragma unroll
+        for (int s = 1; s < S; ++s)
+            if (si == s) {
+                dist = read_lane(d[s], l);
+                node = read_lane(v[s], l);
+            }
     }
     __device__ __forceinline__ int next_unexpanded() const
     {
@@ -375,19 +378,20 @@ __global__ __launch_bounds__(256) void k_hnsw_search(HnswGraphView g, const doub
                                                      double* __restrict__ out_scores, unsigned long long* __restrict__ out_n,
                                                      unsigned long long* __restrict__ stat_evals)
 {
-    // per wave: [ld] f32 query (zero padded), [dim] f64 query, then two (key, node) tables of HNSW_MAX_EF entries
+    // per wave: [ld] f32 query (zero padded), [dim] f64 query, then two (key, node) tables of CAP = 64 S entries
     extern __shared__ double q_lds[];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const uint32_t slot = blockIdx.x * 4 + wave;
     if (slot >= g.n_slots) return;
     const size_t q_words = ((size_t)g.ld / 2 + g.dim + 1) & ~(size_t)1;  // in doubles, 16-byte granules
-    const size_t per_wave = q_words + 3 * (size_t)HNSW_MAX_EF;            // + 2 x (8 B key) + 2 x (4 B node) per entry
+    constexpr uint32_t CAP = 64u * (uint32_t)S;                           // entries the beam list holds (ef <= CAP)
+    const size_t per_wave = q_words + 3 * (size_t)CAP;                    // + 2 x (8 B key) + 2 x (4 B node) per entry
     double* base = q_lds + (size_t)wave * per_wave;
     float* q32 = reinterpret_cast<float*>(base);
     double* q = base + g.ld / 2;
-    unsigned long long* t_key = reinterpret_cast<unsigned long long*>(base + q_words);  // [2][HNSW_MAX_EF]
-    uint32_t* t_node = reinterpret_cast<uint32_t*>(t_key + 2 * HNSW_MAX_EF);             // [2][HNSW_MAX_EF]
+    unsigned long long* t_key = reinterpret_cast<unsigned long long*>(base + q_words);  // [2][CAP]
+    uint32_t* t_node = reinterpret_cast<uint32_t*>(t_key + 2 * CAP);                     // [2][CAP]
     Visited vis;
     vis.attach(g, slot);
 
@@ -430,10 +434,8 @@ __global__ __launch_bounds__(256) void k_hnsw_search(HnswGraphView g, const doub
             unsigned long long exact = ~0ull;
             if (real) exact = row_distance<METRIC>(g.master + (size_t)node * g.dim, q, g.dim);
             n_real += (uint32_t)__popcll(__ballot(real));
-            if (j < (uint32_t)HNSW_MAX_EF) {
-                t_key[j] = exact;
-                t_node[j] = node;
-            }
+            t_key[j] = exact;  // j < CAP by construction
+            t_node[j] = node;
         }
         evals += n_real;
         __builtin_amdgcn_wave_barrier();
@@ -442,8 +444,8 @@ __global__ __launch_bounds__(256) void k_hnsw_search(HnswGraphView g, const doub
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const uint32_t j = s * 64 + lane;
-            const unsigned long long kj = t_key[j < (uint32_t)HNSW_MAX_EF ? j : 0];
-            const uint32_t nj = t_node[j < (uint32_t)HNSW_MAX_EF ? j : 0];
+            const unsigned long long kj = t_key[j];
+            const uint32_t nj = t_node[j];
             if (j < ef && nj != HNSW_NONE) {
                 uint32_t rank = 0;
                 for (uint32_t i = 0; i < ef; ++i) {
@@ -451,8 +453,8 @@ __global__ __launch_bounds__(256) void k_hnsw_search(HnswGraphView g, const doub
                     const uint32_t ni = t_node[i];
                     rank += (ni != HNSW_NONE && (ki < kj || (ki == kj && ni < nj))) ? 1u : 0u;
                 }
-                t_key[HNSW_MAX_EF + rank] = kj;
-                t_node[HNSW_MAX_EF + rank] = nj;
+                t_key[CAP + rank] = kj;
+                t_node[CAP + rank] = nj;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -466,12 +468,12 @@ __global__ __launch_bounds__(256) void k_hnsw_search(HnswGraphView g, const doub
         for (int s = 0; s < S; ++s) {
             const uint32_t r = s * 64 + lane;
             const bool in = r < n_take;
-            const uint32_t node = in ? t_node[HNSW_MAX_EF + r] : 0u;
+            const uint32_t node = in ? t_node[CAP + r] : 0u;
             const bool alive = in && g.live[node] != 0;
             const unsigned long long mk = __ballot(alive);
             const uint32_t pos = kept + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
             if (alive && pos < max_candidates) {
-                const double scaled = __longlong_as_double((long long)t_key[HNSW_MAX_EF + r]);
+                const double scaled = __longlong_as_double((long long)t_key[CAP + r]);
                 out_ids[(size_t)qi * k_stride + pos] = g.node_id[node];
                 out_scores[(size_t)qi * k_stride + pos] = hnsw_score_dev<METRIC>(rust_as_u64(scaled));
             }
@@ -573,7 +575,9 @@ __global__ __launch_bounds__(256) void k_hnsw_insert_search(HnswGraphView g, uin
             uint32_t selv = HNSW_NONE;
             unsigned long long seld = 0;
             uint32_t nsel = 0;
-            unsigned long long kept_lo = 0, kept_hi = 0;  // which beam entries were kept
+            unsigned long long kept_m[S];  // which beam entries were kept (bit ci & 63 of word ci >> 6; static indexing only)
+#pragma unroll
+            for (int s = 0; s < S; ++s) kept_m[s] = 0ull;
             // Exact copies of p (more than M0 of them would otherwise fill every slot and cut the copies off from
             // the rest of the graph) get at most a quarter of the list; the other slots go to distinct rows.
             const uint32_t dup_cap = cap / 4 > 0 ? cap / 4 : 1;
@@ -609,13 +613,17 @@ __global__ __launch_bounds__(256) void k_hnsw_insert_search(HnswGraphView g, uin
                     }
                     ++nsel;
                     ndup += is_dup ? 1u : 0u;
-                    if (ci < 64) kept_lo |= 1ull << ci;
-                    else kept_hi |= 1ull << (ci - 64);
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+                        if ((ci >> 6) == s) kept_m[s] |= 1ull << (ci & 63);
                 }
             }
             if (flags & 2u) {  // back-fill with the closest pruned candidates: keeps the degree at cap
                 for (int ci = 0; ci < total && nsel < cap; ++ci) {
-                    const bool kept = ci < 64 ? ((kept_lo >> ci) & 1ull) : ((kept_hi >> (ci - 64)) & 1ull);
+                    bool kept = false;
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+                        if ((ci >> 6) == s) kept = (kept_m[s] >> (ci & 63)) & 1ull;
                     if (kept) continue;
                     unsigned long long dc;
                     uint32_t cv;
@@ -785,6 +793,9 @@ hipError_t allow_big_lds(K kernel, size_t lds)
     return e;
 }
 
+// sorted-list entries per lane for a beam of width ef: the smallest of 1, 2, 4, 8 with 64 * slots >= ef
+uint32_t hnsw_beam_slots(uint32_t ef) { return ef <= 64 ? 1u : (ef <= 128 ? 2u : (ef <= 256 ? 4u : 8u)); }
+
 int grid_for(const HnswGraphView& g, uint32_t work)
 {
     uint32_t waves = work < g.n_slots ? work : g.n_slots;
@@ -802,7 +813,8 @@ hipError_t launch_hnsw_search(hipStream_t s, int metric, const HnswGraphView& g,
     if (nq == 0) return hipSuccess;
     if (ef == 0 || ef > (uint32_t)HNSW_MAX_EF || g.m0 > 64 || g.m > 64 || max_candidates > k_stride) return hipErrorInvalidValue;
     const size_t q_words = ((size_t)g.ld / 2 + g.dim + 1) & ~(size_t)1;
-    const size_t lds = (size_t)4 * (q_words + 3 * (size_t)HNSW_MAX_EF) * sizeof(double);
+    const uint32_t slots = hnsw_beam_slots(ef);  // list entries per lane: 1, 2, 4 or 8
+    const size_t lds = (size_t)4 * (q_words + 3 * (size_t)64 * slots) * sizeof(double);
     if (lds > HNSW_LDS_MAX) return hipErrorInvalidValue;
     const int grid = grid_for(g, nq);
     return dispatch_metric(metric, [&](auto M) -> hipError_t {
@@ -814,7 +826,12 @@ hipError_t launch_hnsw_search(hipStream_t s, int metric, const HnswGraphView& g,
                                refill, k_stride, out_ids, out_scores, out_n, stat_evals);
             return hipGetLastError();
         };
-        return ef <= 64 ? launch(k_hnsw_search<MM, 1>) : launch(k_hnsw_search<MM, 2>);
+        switch (slots) {
+        case 1: return launch(k_hnsw_search<MM, 1>);
+        case 2: return launch(k_hnsw_search<MM, 2>);
+        case 4: return launch(k_hnsw_search<MM, 4>);
+        default: return launch(k_hnsw_search<MM, 8>);
+        }
     });
 }
 
@@ -835,7 +852,12 @@ hipError_t launch_hnsw_insert_search(hipStream_t s, int metric, const HnswGraphV
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, g, first, n, ef_construction, entry, max_level, flags);
             return hipGetLastError();
         };
-        return ef_construction <= 64 ? launch(k_hnsw_insert_search<MM, 1>) : launch(k_hnsw_insert_search<MM, 2>);
+        switch (hnsw_beam_slots(ef_construction)) {
+        case 1: return launch(k_hnsw_insert_search<MM, 1>);
+        case 2: return launch(k_hnsw_insert_search<MM, 2>);
+        case 4: return launch(k_hnsw_insert_search<MM, 4>);
+        default: return launch(k_hnsw_insert_search<MM, 8>);
+        }
     });
 }
 

@@ -16,7 +16,7 @@
 namespace vl {
 
 constexpr uint32_t HNSW_NONE = 0xFFFFFFFFu;
-constexpr int HNSW_MAX_EF = 128;       // beam width ceiling (two list entries per lane)
+constexpr int HNSW_MAX_EF = 512;       // beam width ceiling (eight sorted-list entries per lane; 1 / 2 / 4 / 8 by the width asked for)
 constexpr int HNSW_MAX_LEVEL = 15;
 
 struct HnswGraphView {

@@ -82,6 +82,10 @@ int regrow(T** p, uint64_t old_count, uint64_t new_count, hipStream_t s, bool ze
 HnswIndex::HnswIndex(uint64_t dim, int metric, const HnswParams& p, int device)
     : dim_(dim), metric_(metric), params_(p), device_(device)
 {
+    // concurrent single searches share walk launches by default (window 0: a lone caller walks alone, at once);
+    // here rather than in create() so that clones start the same way
+    const char* ce = getenv("VL_COALESCE");
+    if (!(ce && ce[0] == '0')) set_coalescing(COALESCE_DEFAULT_BATCH, 0);
 }
 
 int HnswIndex::create(uint64_t dim, int metric, const HnswParams& p, int device, HnswIndex** out)
@@ -95,7 +99,7 @@ int HnswIndex::create(uint64_t dim, int metric, const HnswParams& p, int device,
     }
     if (p.m == 0 || p.m > 64 || p.m0 == 0 || p.m0 > 64 || p.ef_construction == 0 ||
         p.ef_construction > (uint32_t)HNSW_MAX_EF || dim > 3072) {  // the walk keeps the query in LDS: 48 B per dimension per workgroup
-        set_last_error("HNSW parameters out of range (M, M0 <= 64; ef_construction <= 128; dim <= 3072)");
+        set_last_error("HNSW parameters out of range (M, M0 <= 64; 1 <= ef_construction <= " + std::to_string(HNSW_MAX_EF) + "; dim <= 3072)");
         return ERR_INVALID_ARG;
     }
     std::unique_ptr<HnswIndex> h(new HnswIndex(dim, metric, p, device));
@@ -643,7 +647,7 @@ int HnswIndex::ensure_io(WalkScratch* ws, uint64_t nq, uint64_t k) const
 
 // the caller holds mu_ (shared): search_batch's queries whose beam would exceed the walk kernel's
 int HnswIndex::search_exact_fallback(const double* query, uint64_t k, uint64_t* out_ids, double* out_scores,
-                                     uint64_t* out_n) const
+                                     uint64_t* out_n, uint64_t out_limit) const
 {
     *out_n = 0;
     if (live_count_ == 0) return OK;
@@ -669,25 +673,27 @@ int HnswIndex::search_exact_fallback(const double* query, uint64_t k, uint64_t* 
         res.push_back({node_id_[pos[i]], hnsw_score(dist[i], metric_)});
     }
     std::stable_sort(res.begin(), res.end(), [](const Res& a, const Res& b) { return a.score > b.score; });  // :493
-    for (uint64_t i = 0; i < res.size(); ++i) {
+    const uint64_t n_out = std::min<uint64_t>(res.size(), out_limit);
+    for (uint64_t i = 0; i < n_out; ++i) {
         out_ids[i] = res[i].id;
         out_scores[i] = res[i].score;
     }
-    *out_n = res.size();
+    *out_n = n_out;
     return OK;
 }
 
 int HnswIndex::search(const double* query, uint64_t q_len, uint64_t k, int metric, uint32_t ef, uint64_t* out_ids,
-                      double* out_scores, uint64_t* out_n) const
+                      double* out_scores, uint64_t* out_n, uint64_t out_stride) const
 {
+    const uint64_t out_limit = out_stride ? out_stride : k;
     // Walk launches of different callers run side by side (each borrows its own WalkScratch); a launch of one query
     // still leaves most of the chip idle, so callers that arrive together can also share a launch.  Everything that can fail without walking is
     // settled on the calling thread; compatible requests (same k and ef; the metric is the index's) are walked
     // by one search_batch(), each caller receiving exactly what its own search_batch(nq = 1) would return.
     if (!co_.enabled() || !out_n || q_len != dim_ || metric != metric_ || k == 0 || !query || !out_ids || !out_scores ||
-        k > (uint64_t)HNSW_MAX_EF)
-        return search_batch(query, 1, q_len, k, metric, ef, out_ids, out_scores, out_n);
-    CoalesceReq r{query, k, ef, out_ids, out_scores, out_n};
+        k > (uint64_t)HNSW_MAX_EF || ef > (uint32_t)HNSW_MAX_EF)
+        return search_batch(query, 1, q_len, k, metric, ef, out_ids, out_scores, out_n, out_stride);
+    CoalesceReq r{query, k, ef, out_ids, out_scores, out_n, out_limit};
     co_.run(
         r, [](const CoalesceReq& a, const CoalesceReq& o) { return a.k == o.k && a.ef == o.ef; },
         [this](std::vector<CoalesceReq*>& batch) {
@@ -702,11 +708,12 @@ int HnswIndex::search(const double* query, uint64_t q_len, uint64_t k, int metri
                 if (rc == OK) {
                     for (uint64_t i = 0; i < nq; ++i) {
                         CoalesceReq* o = batch[i];
-                        for (uint64_t j = 0; j < cnt[i]; ++j) {
+                        const uint64_t m = std::min<uint64_t>(cnt[i], o->out_limit);
+                        for (uint64_t j = 0; j < m; ++j) {
                             o->out_ids[j] = ids[i * kk + j];
                             o->out_scores[j] = scores[i * kk + j];
                         }
-                        *o->out_n = cnt[i];
+                        *o->out_n = m;
                         o->rc = OK;
                     }
                     return;
@@ -714,7 +721,7 @@ int HnswIndex::search(const double* query, uint64_t q_len, uint64_t k, int metri
             } catch (...) {  // host allocation failed: the callers are answered one by one below
             }
             for (CoalesceReq* o : batch) {  // alone, or the batch failed as a whole: per-caller status
-                o->rc = search_batch(o->query, 1, dim_, o->k, metric_, o->ef, o->out_ids, o->out_scores, o->out_n);
+                o->rc = search_batch(o->query, 1, dim_, o->k, metric_, o->ef, o->out_ids, o->out_scores, o->out_n, o->out_limit);
                 if (o->rc != OK) o->err = last_error();
             }
         });
@@ -723,11 +730,16 @@ int HnswIndex::search(const double* query, uint64_t q_len, uint64_t k, int metri
 }
 
 int HnswIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_len, uint64_t k, int metric, uint32_t ef,
-                            uint64_t* out_ids, double* out_scores, uint64_t* out_n) const
+                            uint64_t* out_ids, double* out_scores, uint64_t* out_n, uint64_t out_stride) const
 {
+    const uint64_t os = out_stride ? out_stride : k;  // the caller's row stride = the most it takes per query
     if (!out_n && nq) return ERR_INVALID_ARG;
     for (uint64_t i = 0; i < nq; ++i) out_n[i] = 0;
     if (metric < 0 || metric > 3) return ERR_INVALID_ARG;
+    if (ef > (uint32_t)HNSW_MAX_EF) {  // our own knob (the reference has none): refused, never silently narrowed
+        set_last_error("HNSW search: ef = " + std::to_string(ef) + " exceeds the walk's beam ceiling of " + std::to_string(HNSW_MAX_EF));
+        return ERR_INVALID_ARG;
+    }
     std::shared_lock<RwLock> lk(mu_);
     if (q_len != dim_) {  // :416-421, checked even when the index is empty
         set_dim_mismatch(dim_, q_len);
@@ -750,16 +762,14 @@ int HnswIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_len, 
     // recall@10 is 0.96 instead of 0.78 at N = 1 M for about the same batch throughput.
     uint64_t ef_walk = ef ? std::max<uint64_t>(max_candidates, ef) : std::max<uint64_t>(max_candidates, min_beam_.load());
     if (ef_walk > (uint64_t)HNSW_MAX_EF) {
-        if (max_candidates > (uint64_t)HNSW_MAX_EF) {
-            // A beam wider than the walk kernel holds (ef = min(k, len) > 128): answer from the row store with
-            // the exact scan instead -- the true nearest neighbours in Metric::distance order, i.e. what a perfect
-            // walk would return, post-processed exactly like a walk's beam below.
-            lk.unlock();
-            for (uint64_t qi = 0; qi < nq; ++qi)
-                VL_TRY(search_exact_fallback(queries + qi * dim_, k, out_ids + qi * k, out_scores + qi * k, out_n + qi));
-            return OK;
-        }
-        ef_walk = HNSW_MAX_EF;
+        // Only min(k, len) can have pushed the beam past the walk kernel's ceiling (an explicit ef beyond it was
+        // refused above, the opt-in floor is capped at it): answer from the row store with the exact scan instead --
+        // the true nearest neighbours in Metric::distance order, i.e. what a perfect walk would return,
+        // post-processed exactly like a walk's beam below.
+        lk.unlock();
+        for (uint64_t qi = 0; qi < nq; ++qi)
+            VL_TRY(search_exact_fallback(queries + qi * dim_, k, out_ids + qi * os, out_scores + qi * os, out_n + qi, os));
+        return OK;
     }
 
     VL_HIP(hipSetDevice(device_));
@@ -806,9 +816,9 @@ int HnswIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_len, 
     stat_queries_.fetch_add(nq, std::memory_order_relaxed);
     const unsigned long long* h_n = ws->h_out + 2 * nq * kd;
     for (uint64_t qi = 0; qi < nq; ++qi) {
-        const uint64_t m = std::min<uint64_t>(h_n[qi], kd);
-        std::memcpy(out_ids + qi * k, ws->h_out + qi * kd, m * sizeof(uint64_t));
-        std::memcpy(out_scores + qi * k, ws->h_out + nq * kd + qi * kd, m * sizeof(double));
+        const uint64_t m = std::min<uint64_t>({(uint64_t)h_n[qi], kd, os});
+        std::memcpy(out_ids + qi * os, ws->h_out + qi * kd, m * sizeof(uint64_t));
+        std::memcpy(out_scores + qi * os, ws->h_out + nq * kd + qi * kd, m * sizeof(double));
         out_n[qi] = m;
     }
     return OK;

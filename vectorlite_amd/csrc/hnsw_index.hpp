@@ -54,11 +54,12 @@ public:
         uint64_t* out_ids;
         double* out_scores;
         uint64_t* out_n;
+        uint64_t out_limit;  // entries the caller's buffers hold
         int rc = 6;  // ERR_DEVICE until the walk answers it
         std::string err = "coalesced walk ended without answering this request";
         bool done = false;
     };
-    // concurrent single-query search() calls share walk launches (coalescer.hpp); 0 / 1 = off (default)
+    // concurrent single-query search() calls share walk launches (coalescer.hpp); 0 / 1 = off; on by default (create())
     void set_coalescing(int max_batch, int window_us) { co_.configure(max_batch, window_us, 4096); }
     void coalesce_stats(uint64_t* batches, uint64_t* queries) const { co_.stats(batches, queries); }
 
@@ -69,10 +70,13 @@ public:
     int add_bulk(const uint64_t* ids, const double* values, uint64_t n, bool values_on_device);
     int remove(uint64_t id);
     // ef == 0: the reference's rule ef = min(k, len) (src/index/hnsw.rs:437,454); ef > 0: own extension
+    // out_stride (0 = k): the caller's buffers hold out_stride entries per query -- rows are out_stride apart and at most
+    // out_stride results are written per row, while the WALK still runs with the caller's k (ef = min(k, len)): the
+    // first out_stride entries of what the uncapped call would return (vl_index_search_cap / _batch_cap)
     int search(const double* query, uint64_t q_len, uint64_t k, int metric, uint32_t ef, uint64_t* out_ids,
-               double* out_scores, uint64_t* out_n) const;
+               double* out_scores, uint64_t* out_n, uint64_t out_stride = 0) const;
     int search_batch(const double* queries, uint64_t nq, uint64_t q_len, uint64_t k, int metric, uint32_t ef,
-                     uint64_t* out_ids, double* out_scores, uint64_t* out_n) const;
+                     uint64_t* out_ids, double* out_scores, uint64_t* out_n, uint64_t out_stride = 0) const;
     uint64_t len() const;
     uint64_t dimension() const { return dim_; }
     int device() const { return device_; }
@@ -105,7 +109,8 @@ private:
     void release_scratch(WalkScratch* ws) const;
     void drop_scratch_pool();                             // the graph's capacity changed (caller holds the unique lock)
     int ensure_io(WalkScratch* ws, uint64_t nq, uint64_t k) const;
-    int search_exact_fallback(const double* query, uint64_t k, uint64_t* out_ids, double* out_scores, uint64_t* out_n) const;
+    int search_exact_fallback(const double* query, uint64_t k, uint64_t* out_ids, double* out_scores, uint64_t* out_n,
+                              uint64_t out_limit) const;
 
     const uint64_t dim_;
     const int metric_;

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -212,14 +213,52 @@ int MultiFlatIndex::add_bulk(const uint64_t* ids, const double* values, uint64_t
     if (n == 0) return OK;
     if (!ids || (!values && dim_)) return ERR_INVALID_ARG;
     std::unique_lock<RwLock> lk(mu_);
+    if (const int brc = refuse_if_broken()) return brc;
     const int P = (int)parts_.size();
     if (values_on_device && src_device < 0) src_device = parts_[0]->device();
     std::vector<PartOutcome> oc((size_t)P);
 
+    // Test hook: VL_MULTI_INJECT_ADD_FAIL=<part> makes that part's share of the next bulk adds fail (after the pre-flight).
+    int inject = -1;
+    if (const char* inj = getenv("VL_MULTI_INJECT_ADD_FAIL"))
+        if (*inj) inject = atoi(inj);
+    auto part_add = [&](int i, const uint64_t* pi, const double* pv, uint64_t cnt) -> int {
+        if (i == inject) {
+            set_last_error("injected add failure on part " + std::to_string(i) + " (VL_MULTI_INJECT_ADD_FAIL)");
+            return (int)ERR_DEVICE;
+        }
+        return parts_[(size_t)i]->add_bulk(pi, pv, cnt, validate, values_on_device, src_device);
+    };
+    std::vector<uint64_t> len0((size_t)P);
+    for (int p = 0; p < P; ++p) len0[(size_t)p] = parts_[(size_t)p]->len();
+    // A fan-out is all-or-nothing (advisor, round 3): (1) every part makes room BEFORE any part takes a row -- running out
+    // of memory, the one failure a healthy device produces, then leaves every part as it was; (2) if a part fails anyway,
+    // every part forgets the rows this call gave it, so replicas never diverge and a sharded index never holds a
+    // non-prefix subset of the batch.
+    auto roll_back = [&]() {
+        for (int p = 0; p < P; ++p) parts_[(size_t)p]->truncate(len0[(size_t)p]);
+    };
+
     if (mode_ == REPLICAS) {  // the same n sequential adds on every replica: identical state, identical outcome
-        run_parts([&](int i) {
-            guarded(oc[(size_t)i], [&]() { return parts_[(size_t)i]->add_bulk(ids, values, n, validate, values_on_device, src_device); });
-        });
+        run_parts([&](int i) { guarded(oc[(size_t)i], [&]() { return parts_[(size_t)i]->reserve(len0[(size_t)i] + n); }); });
+        {
+            const int rc = publish_first_error(oc);
+            if (rc != OK) return rc;  // nothing was added anywhere
+        }
+        run_parts([&](int i) { guarded(oc[(size_t)i], [&]() { return part_add(i, ids, values, n); }); });
+        bool same = true;
+        const uint64_t len_a = parts_[0]->len();
+        for (int p = 1; p < P; ++p) same = same && oc[(size_t)p].rc == oc[0].rc && parts_[(size_t)p]->len() == len_a;
+        if (!same) {  // a replica failed where the others did not: back to the common state, report the failure
+            roll_back();
+            for (int p = 0; p < P; ++p)
+                if (oc[(size_t)p].rc != OK && oc[(size_t)p].rc != ERR_DUP_ID) {
+                    set_last_error(oc[(size_t)p].err + " (no replica kept a row of this call)");
+                    return oc[(size_t)p].rc;
+                }
+            set_last_error("the replicas disagreed on a bulk add (no replica kept a row of this call)");
+            return ERR_DEVICE;
+        }
         return publish_first_error(oc);
     }
 
@@ -260,34 +299,67 @@ int MultiFlatIndex::add_bulk(const uint64_t* ids, const double* values, uint64_t
     if (given < n_take) {  // (cannot happen: the rooms add up to at least n_take) -- never drop rows
         count[(size_t)P - 1] += n_take - given;
     }
+    run_parts([&](int i) {  // pre-flight: room on every shard before any shard takes a row
+        const size_t p = (size_t)i;
+        if (count[p] == 0) return;
+        guarded(oc[p], [&]() { return parts_[p]->reserve(lens[p] + count[p]); });
+    });
+    {
+        const int rc = publish_first_error(oc);
+        if (rc != OK) return rc;  // nothing was added anywhere
+    }
     run_parts([&](int i) {
         const size_t p = (size_t)i;
         if (count[p] == 0) return;
         // ids were validated against the whole index above; the shard's own check keeps its id table current
-        guarded(oc[p], [&]() {
-            return parts_[p]->add_bulk(ids + start[p], values ? values + start[p] * dim_ : nullptr, count[p], validate,
-                                       values_on_device, src_device);
-        });
+        guarded(oc[p], [&]() { return part_add(i, ids + start[p], values ? values + start[p] * dim_ : nullptr, count[p]); });
     });
+    {
+        const int rc = publish_first_error(oc);
+        if (rc != OK) {  // a shard failed: no shard keeps its run (the index would hold a non-prefix subset of the batch)
+            const std::string msg = last_error();
+            roll_back();
+            set_last_error(msg + " (no row of this call was kept)");
+            return rc;
+        }
+    }
     for (int p = 0; p < P; ++p) {
-        if (count[(size_t)p] == 0 || oc[(size_t)p].rc != OK) continue;
+        if (count[(size_t)p] == 0) continue;
         std::vector<uint64_t>& sq = seq_[(size_t)p];
         for (uint64_t j = 0; j < count[(size_t)p]; ++j) sq.push_back(next_seq_ + start[(size_t)p] + j);
     }
     next_seq_ += n_take;
-    const int rc = publish_first_error(oc);
-    if (rc != OK) return rc;
     if (rc_after != OK) set_last_error(dup_msg);
     return rc_after;
+}
+
+int MultiFlatIndex::refuse_if_broken() const
+{
+    if (!broken_.load(std::memory_order_relaxed)) return OK;
+    set_last_error("this multi-GPU handle failed on part of its GPUs during a delete and no longer answers (its parts disagree); rebuild it");
+    return ERR_DEVICE;
 }
 
 int MultiFlatIndex::remove(uint64_t id)
 {
     std::unique_lock<RwLock> lk(mu_);
+    if (const int brc = refuse_if_broken()) return brc;
     const int P = (int)parts_.size();
     std::vector<PartOutcome> oc((size_t)P);
     std::vector<std::vector<uint64_t>> gone((size_t)P);
-    run_parts([&](int i) { guarded(oc[(size_t)i], [&]() { return parts_[(size_t)i]->remove_report(id, &gone[(size_t)i]); }); });
+    const char* inj = getenv("VL_MULTI_INJECT_DELETE_FAIL");  // test hook: that part's delete fails
+    const int inject = inj && *inj ? atoi(inj) : -1;
+    run_parts([&](int i) {
+        guarded(oc[(size_t)i], [&]() {
+            if (i == inject) {
+                set_last_error("injected delete failure (VL_MULTI_INJECT_DELETE_FAIL)");
+                return (int)ERR_DEVICE;
+            }
+            return parts_[(size_t)i]->remove_report(id, &gone[(size_t)i]);
+        });
+    });
+    for (int p = 0; p < P; ++p)
+        if (oc[(size_t)p].rc != OK) broken_.store(true);  // a compaction died half way on that part: nothing to roll back to
     if (mode_ == ROW_SHARDS)
         for (int p = 0; p < P; ++p)
             for (uint64_t pos : gone[(size_t)p])  // descending: each erase leaves the earlier positions in place
@@ -319,6 +391,7 @@ int MultiFlatIndex::search(const double* query, uint64_t q_len, uint64_t k, int 
 {
     if (!out_n) return ERR_INVALID_ARG;
     std::shared_lock<RwLock> lk(mu_);
+    if (const int brc = refuse_if_broken()) return brc;
     if (mode_ == REPLICAS) {
         const int i = pick_replica();
         inflight_[(size_t)i]->fetch_add(1, std::memory_order_relaxed);
@@ -346,6 +419,7 @@ int MultiFlatIndex::search_batch(const double* queries, uint64_t nq, uint64_t q_
         return ERR_INVALID_ARG;
     }
     std::shared_lock<RwLock> lk(mu_);
+    if (const int brc = refuse_if_broken()) return brc;
     if (mode_ == ROW_SHARDS) return shard_search(queries, nq, q_len, k, metric, out_pos, out_ids, out_scores, out_n);
 
     // REPLICAS: one contiguous run of queries per replica (row stride k in every output, so the runs are plain offsets)

@@ -110,6 +110,10 @@ private:
     mutable std::vector<std::unique_ptr<std::atomic<int>>> inflight_;       // REPLICAS: searches running on each replica
     mutable std::vector<std::unique_ptr<std::atomic<uint64_t>>> answered_;  // searches each part has answered
     mutable std::atomic<uint32_t> rr_{0};
+    // a delete that failed on some parts only (the device died in the middle of a compaction) cannot be taken back: the
+    // parts no longer agree, so the handle refuses every later call instead of serving divergent answers
+    std::atomic<bool> broken_{false};
+    int refuse_if_broken() const;
 
     // ROW_SHARDS exchange: a pinned host block of all parts' records + a merger on part 0's GPU per search IN FLIGHT.
     // The reference serves many readers at once (RwLock::read, src/client.rs:398): concurrent searches of a sharded handle
