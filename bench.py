@@ -91,6 +91,7 @@ def parse_args(argv=None):
     p.add_argument("--c3-shards", type=int, default=8)
     p.add_argument("--c3-dim", type=int, default=768)
     p.add_argument("--c3-batch", type=int, default=1024)
+    p.add_argument("--no-c3-full", action="store_true", help="skip config 3 at its own size on one card (8 shards of the 10 M x 768 corpus)")
     p.add_argument("--c4-rows", type=int, default=1_000_000)
     p.add_argument("--c4-queries", type=int, default=1000)
     p.add_argument("--block-cap-s", type=float, default=60.0, help="soft cap per later block: steps still to run are skipped")
@@ -365,7 +366,22 @@ def c3_rows_for(rank: int, world: int, total: int, shards_at_n1: int):
     return starts[r], starts[r + 1], (total if world > 1 else starts[1])
 
 
-def run_c3(V, torch, dist, args, dev, dev_index, rank, world, rehearse, k, cap_s):
+def build_c3_shard(V, torch, dev, dev_index, dim, lo, hi):
+    """Rows [lo, hi) of config 3's corpus as one flat handle: a function of the GLOBAL row range, so the same rows come out
+    whichever rank (or one-card shard list) builds them."""
+    shard = V.FlatIndex(dim, device=dev_index)
+    shard.reserve(hi - lo)
+    pos = lo
+    while pos < hi:
+        c = min(250_000, hi - pos)
+        x = gen_unit_rows(torch, dev, c, dim, 424242 + pos)
+        shard.add_rows(ids_for(pos, c), x, validate=False)
+        pos += c
+        del x
+    return shard
+
+
+def run_c3(V, torch, dist, args, dev, dev_index, rank, world, rehearse, k, cap_s, prebuilt=None):
     """BASELINE config 3 (flat L2, dim 768, 1024-query batches, rows sharded over the ranks): every rank answers the
     batch on its own rows with the single-GPU pipeline, ONE ncclAllGather inside libvectorlite_amd.so
     (vl_shard_search_batch) exchanges the per-shard top-k, a device kernel merges.  Collective: every rank calls it."""
@@ -373,15 +389,7 @@ def run_c3(V, torch, dist, args, dev, dev_index, rank, world, rehearse, k, cap_s
     t_block = time.perf_counter()
     dim, nq, metric = args.c3_dim, args.c3_batch, 1
     lo, hi, corpus = c3_rows_for(rank, world, args.c3_rows, args.c3_shards)
-    shard = V.FlatIndex(dim, device=dev_index)
-    shard.reserve(hi - lo)
-    pos = lo
-    while pos < hi:
-        c = min(250_000, hi - pos)
-        x = gen_unit_rows(torch, dev, c, dim, 424242 + pos)  # a function of the global row range
-        shard.add_rows(ids_for(pos, c), x, validate=False)
-        pos += c
-        del x
+    shard = prebuilt if prebuilt is not None else build_c3_shard(V, torch, dev, dev_index, dim, lo, hi)
     Qs = unit_queries(2468, nq, dim)  # the same batch on every rank
     comm = None
     if rehearse:  # ranks share one card and RCCL refuses that: the records travel by gloo, the merge is the same kernel
@@ -452,6 +460,7 @@ def run_c3(V, torch, dist, args, dev, dev_index, rank, world, rehearse, k, cap_s
         li, ls = shard.search_arrays(Qs[qi], k, metric)
         mine = [(int(i), float(sc)) for i, sc, pp in zip(si[qi], ss[qi], sp[qi]) if sh.offset <= int(pp) < sh.offset + (hi - lo)]
         own_ok += int(mine == list(zip(li.tolist(), ls.tolist()))[: len(mine)])
+    nccl_ranks_seen = comm.world if comm is not None else None  # vl_comm_world: what RCCL's communicator itself reports
     if comm is not None:
         comm.close()
     rows_rank = hi - lo
@@ -466,6 +475,7 @@ def run_c3(V, torch, dist, args, dev, dev_index, rank, world, rehearse, k, cap_s
         "transport": ("gloo records + device merge (rehearsal on one card)" if rehearse else
                       "RCCL: one ncclAllGather per batch inside the library (vl_shard_search_batch), device merge"),
         "collective_bytes_per_rank": 8 * (4 + nq + 3 * nq * min(k, rows_rank)),
+        "nccl_ranks_seen": nccl_ranks_seen,
         "identical_on_every_rank": same, "own_rows_match_single_search": f"{own_ok}/{n_own}",
         "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS,
                      "kernel": "k_mfma_rows (sampling pass + pass-1 stages + thresholds / candidate select), per GPU",
@@ -494,8 +504,70 @@ def run_c3(V, torch, dist, args, dev, dev_index, rank, world, rehearse, k, cap_s
                                         "ncclAllGather": round(prof["allgather_ms"] / c, 4),
                                         "merge_kernel_and_d2h": round(prof["merge_ms"] / c, 4),
                                         "note": "HIP events on the exchange stream (vl_comm_profile_read), rank 0"}
-    del sh, shard
+    del sh
+    if prebuilt is None:
+        del shard
     torch.cuda.empty_cache()
+    return out
+
+
+def run_c3_full_one_card(V, torch, args, dev, dev_index, k, shards, starts):
+    """BASELINE config 3 AT ITS OWN SIZE on one card: the 10 M x 768 corpus as `--c3-shards` contiguous row shards (separate
+    flat handles on this GPU), the 1024-query Euclidean batch through vl_shard_search_local_dev on every shard and ONE
+    vl_shard_merge over the records -- the calls an N-rank run makes (csrc/shard_comm.cpp), minus the wire.  The shards run one
+    after the other here (one card), so per-shard time is what one rank of the N-GPU run spends; the merge is the real
+    N-record merge."""
+    from vectorlite_amd.sharded import OneProcessShards
+    dim, nq, metric = args.c3_dim, args.c3_batch, 1
+    world = len(shards)
+    total = starts[-1]
+    sh = OneProcessShards(shards)
+    assert sh.total == total and sh.offsets == starts[:-1]
+    Qs = unit_queries(2468, nq, dim)
+    dQ = torch.from_numpy(np.ascontiguousarray(Qs)).to(dev)
+    sh.search_batch(dQ[:128].contiguous(), k, metric)   # every shard's bf16 copy and scratch
+    ids, scores, cnt, gpos = sh.search_batch(dQ, k, metric, with_positions=True)
+    torch.cuda.synchronize()
+    reps, local, merge = 3, [], []
+    tw = time.perf_counter()
+    for _ in range(reps):
+        t = {}
+        i2, s2, n2 = sh.search_batch(dQ, k, metric, timings=t)
+        local.append(t["local_ms"])
+        merge.append(t["merge_ms"])
+    wall = (time.perf_counter() - tw) / reps
+    local = np.asarray(local)
+    same = bool(np.array_equal(i2, ids) and np.array_equal(s2, scores))
+    # every shard's rows in the merged answer are what that shard's own single search returns for them, in order
+    own_ok, n_own = 0, 4
+    for qi in range(n_own):
+        ok = True
+        for r, shd in enumerate(shards):
+            li, ls = shd.search_arrays(Qs[qi], k, metric)
+            mine = [(int(i), float(sc)) for i, sc, pp in zip(ids[qi], scores[qi], gpos[qi]) if starts[r] <= int(pp) < starts[r + 1]]
+            ok = ok and mine == list(zip(li.tolist(), ls.tolist()))[: len(mine)]
+        own_ok += int(ok)
+    sorted_ok = bool(all(scores[q, j - 1] >= scores[q, j] for q in range(nq) for j in range(1, scores.shape[1])))
+    flops = 2.0 * nq * total * dim
+    per_shard = float(local.mean())
+    out = {"workload": (f"flat euclidean batched search, corpus {total} x {dim} as {world} contiguous row shards on ONE card, "
+                        f"{nq} queries per batch (resident in HBM), k={k}: vl_shard_search_local_dev x {world} + vl_shard_merge"),
+           "shards": world, "rows_per_shard": [starts[r + 1] - starts[r] for r in range(world)],
+           "ms_per_batch_per_shard": round(per_shard, 3),
+           "ms_per_batch_per_shard_min_max": [round(float(local.min()), 3), round(float(local.max()), 3)],
+           "merge_ms_for_all_records": round(float(np.mean(merge)), 3),
+           "ms_per_batch_all_shards_one_after_the_other": round(wall * 1e3, 3),
+           "value": round(nq / wall, 1), "unit": "queries/s",
+           "second_pass_identical": same, "scores_sorted": sorted_ok,
+           "every_shards_rows_match_its_own_single_search": f"{own_ok}/{n_own}",
+           "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS,
+                        "whole_call_one_card": {"achieved": round(flops / wall / 1e12, 1), "frac": round(flops / wall / 1e12 / MFMA_PEAK_TFLOPS, 4)},
+                        "traffic": None},
+           "n_gpu_estimate_from_these_parts": {
+               "ms_per_batch": round(float(local.max(axis=1).mean()) + float(np.mean(merge)), 3),
+               "note": f"slowest shard + the {world}-record merge; the ncclAllGather of {world} x {8 * (4 + nq + 3 * nq * k)} bytes is NOT in it "
+                       "(no multi-GPU node): arithmetic from single-card parts, not a scaling measurement"}}
+    del dQ
     return out
 
 
@@ -839,6 +911,8 @@ def run_rank(args) -> int:
         wd.daemon = True
         wd.start()
         block("c3_row_sharded", lambda: other.__setitem__("c3_row_sharded", c3_all_ranks()))
+        out["nccl_ranks_seen"] = (other.get("c3_row_sharded") or {}).get("nccl_ranks_seen")  # did RCCL itself see N ranks?
+        publish()
         wd.cancel()
 
     # ---- CPU baseline: the oracle (reference-faithful restatement), bounded sample ---------------
@@ -1067,7 +1141,63 @@ def run_rank(args) -> int:
                                     "traffic": None}}
 
     def c3_block():
-        other["c3_shard"] = run_c3(V, torch, None, args, dev, dev_index, 0, 1, False, k, args.block_cap_s)
+        # config 3's whole corpus as --c3-shards row shards on this card when it fits (10 M x 768: 107 GB with the bf16 copies);
+        # shard 0 IS the one-rank shard of the c3_shard leg (rows are a function of the global row range)
+        parts = max(1, args.c3_shards)
+        base, rem = divmod(args.c3_rows, parts)
+        starts = [0]
+        for r in range(parts):
+            starts.append(starts[-1] + base + (1 if r < rem else 0))
+        need = args.c3_rows * args.c3_dim * (8 + 4 + 2) * 1.06 + 4e9
+        free_b, _tot = torch.cuda.mem_get_info(dev)
+        full = (not args.no_c3_full) and free_b > need
+        shards = [build_c3_shard(V, torch, dev, dev_index, args.c3_dim, starts[r], starts[r + 1]) for r in range(parts if full else 1)]
+        torch.cuda.synchronize()
+        other["c3_shard"] = run_c3(V, torch, None, args, dev, dev_index, 0, 1, False, k, args.block_cap_s, prebuilt=shards[0])
+        out["nccl_ranks_seen"] = other["c3_shard"].get("nccl_ranks_seen")
+        publish()
+        if full:
+            other["c3_full_one_card"] = run_c3_full_one_card(V, torch, args, dev, dev_index, k, shards, starts)
+        else:
+            other["c3_full_one_card"] = {"skipped": ("--no-c3-full" if args.no_c3_full else
+                                                     f"needs ~{need / 1e9:.0f} GB of device memory, {free_b / 1e9:.0f} GB free")}
+        del shards
+        torch.cuda.empty_cache()
+
+    # ---- the reference's many-readers usage (src/client.rs:398, src/server.rs:269): 16 host threads, single searches, default handle ----
+    def concurrent_block():
+        T, per = 16, 30
+        Qt = unit_queries(1616, T * per, dim)
+        lone = [idx.search_arrays(Qt[t * per], k, metric) for t in range(T)]
+        b0, q0 = idx.coalesce_stats()
+        res = [None] * (T * per)
+        lat = [0.0] * (T * per)
+        bar = threading.Barrier(T + 1)
+
+        def worker(t):
+            bar.wait()
+            for i in range(t * per, (t + 1) * per):
+                ta = time.perf_counter()
+                res[i] = idx.search_arrays(Qt[i], k, metric)
+                lat[i] = time.perf_counter() - ta
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+        for x in th:
+            x.start()
+        bar.wait()
+        tc = time.perf_counter()
+        for x in th:
+            x.join()
+        el = time.perf_counter() - tc
+        b1, q1 = idx.coalesce_stats()
+        same = sum(int(res[t * per][0].tolist() == lone[t][0].tolist() and res[t * per][1].tolist() == lone[t][1].tolist()) for t in range(T))
+        la = np.sort(np.asarray(lat)) * 1e3
+        out["concurrent_16_threads"] = {
+            "threads": T, "queries": T * per, "value": round(T * per / el, 1), "unit": "queries/s",
+            "latency_ms": {"mean": round(float(la.mean()), 3), "p50": round(float(la[len(la) // 2]), 3), "p99": round(float(la[int(len(la) * 0.99)]), 3)},
+            "identical_to_lone_search": f"{same}/{T}",
+            "passes": int(b1 - b0), "queries_per_pass": round((q1 - q0) / max(b1 - b0, 1), 2),
+            "handle": "as created: coalescing on by default (max 256 per pass, window 0); lone callers are the timed region above",
+            "note": "concurrent callers share slab passes (bf16 MFMA filter + exact f64 finalize): every answer is the lone search's"}
 
     def c4_block():
         other["c4_hnsw"] = run_c4(V, torch, args, dev, dev_index, k, args.block_cap_s, log)
@@ -1129,6 +1259,7 @@ def run_rank(args) -> int:
     if extras:
         block("value_sustained", sustained_block)
         block("fast_vs_exact_full_size", exact_block)
+        block("concurrent_16_threads", concurrent_block)
         if not args.no_other_configs:
             block("c2", c2_block)
             block("c5", c5_block)

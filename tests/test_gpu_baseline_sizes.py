@@ -6,6 +6,10 @@
       (blockIdx.y > 0) and the 1 024-query host pass boundary of the MFMA filter
   C3  one rank's shard of the row-sharded config: 1 250 000 x 768, Euclidean, 1 024 queries in one batch: against
       single search() on 32 sampled queries
+  C3 at its own size (round 4): 10 000 000 x 768 as 8 contiguous row shards on ONE card (107 GB), the 1 024-query
+      Euclidean batch through vl_shard_search_local_dev x 8 + vl_shard_merge on the 8 records -- the calls an 8-rank run
+      makes, minus the wire -- against ONE unsharded index of the same 10 M rows (ids, global positions, f64 scores ==),
+      with ties planted across shard boundaries; the same pipeline at 8 x 100 000 rows against the oracle on the union
   headline  N = 10 000 000 x 384: the f32 fast path against the exact f64 path (property; the oracle would need
       minutes per query), and a 300-query MFMA batch against single search().
 
@@ -195,3 +199,138 @@ def test_dim768_batch_of_2048_runs_as_two_sequences_on_the_mfma_filter(V):
     for qi in list(range(0, nq, 97)) + [1023, 1024, 2047]:
         si, ss = idx.search_arrays(Q[qi], k, 1)
         assert bi[qi].tolist() == si.tolist() and bs[qi].tolist() == ss.tolist(), qi
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 3 at its own size: N = 10 M, dim = 768, 1024-query Euclidean batch, 8 row shards (BASELINE.json configs[2];
+# semantics: src/index/flat.rs:98-119 on the union of the shards)
+# ---------------------------------------------------------------------------------------------------------------------
+def _device_rows(n, dim, seed, chunk, plant=None, first_row=0):
+    """bench.py's generator, chunk by chunk: yields (global start row, f64 device tensor).  plant: {global row: vector}."""
+    import torch
+    done = ci = 0
+    while done < n:
+        c = min(chunk, n - done)
+        g = torch.Generator(device="cuda:0")
+        g.manual_seed(seed + ci)
+        x = torch.randn((c, dim), dtype=torch.float64, device="cuda:0", generator=g)
+        x /= torch.linalg.vector_norm(x, dim=1, keepdim=True)
+        for row, vec in (plant or {}).items():
+            if first_row + done <= row < first_row + done + c:
+                x[row - first_row - done] = torch.from_numpy(np.ascontiguousarray(vec)).to("cuda:0")
+        yield first_row + done, x
+        done += c
+        ci += 1
+
+
+def _build_unsharded_and_shards(V, n, dim, world, seed, chunk, plant):
+    """(factory for the unsharded index, factory for the list of shard handles): the SAME rows in the same order -- chunk
+    boundaries coincide with shard boundaries, so both forms ingest identical tensors."""
+    import torch
+    per = n // world
+    assert per * world == n and per % chunk == 0
+
+    def unsharded():
+        idx = V.FlatIndex(dim)
+        idx.reserve(n)
+        for r in range(world):
+            for start, x in _device_rows(per, dim, seed + 1000 * r, chunk, plant, first_row=r * per):
+                idx.add_rows(ids_for(start, x.shape[0]), x, validate=False)
+                del x
+        torch.cuda.synchronize()
+        return idx
+
+    def shards():
+        out = []
+        for r in range(world):
+            s = V.FlatIndex(dim)
+            s.reserve(per)
+            for start, x in _device_rows(per, dim, seed + 1000 * r, chunk, plant, first_row=r * per):
+                s.add_rows(ids_for(start, x.shape[0]), x, validate=False)
+                del x
+            out.append(s)
+        torch.cuda.synchronize()
+        return out
+
+    return unsharded, shards
+
+
+def _tie_plan(rng, n, world, dim):
+    """One vector stored in four places that straddle shard boundaries (last row of shard 0, first row of shard 1, a row in
+    the middle of shard 5, the very last row) and a second one in shards 2 and 3: the reference's stable sort ranks equal
+    scores by storage position (src/index/flat.rs:116), i.e. by shard, then by position inside the shard."""
+    per = n // world
+    t1, t2 = unit_rows(rng, 2, dim)
+    return {per - 1: t1, per: t1, 5 * per + per // 2: t1, n - 1: t1, 3 * per - 1: t2, 3 * per: t2}, t1, t2
+
+
+def test_config3_pipeline_at_8_x_100k_against_the_oracle_on_the_union(V, O):
+    import torch
+    from vectorlite_amd.sharded import OneProcessShards
+    n, dim, nq, k, world = 800_000, 768, 1024, 10, 8
+    per = n // world
+    plant, t1, t2 = _tie_plan(np.random.default_rng(31), n, world, dim)
+    _, make_shards = _build_unsharded_and_shards(V, n, dim, world, seed=700, chunk=per, plant=plant)
+    shards = make_shards()
+    sh = OneProcessShards(shards)
+    assert sh.total == n and sh.offsets == [r * per for r in range(world)]
+    Q = unit_rows(np.random.default_rng(4321), nq, dim)
+    Q[7], Q[500] = t1, t2                     # the queries that hit the planted ties (Euclidean score 1.0 on every copy)
+    dQ = torch.from_numpy(Q).to("cuda:0")
+    ids, scores, cnt, gpos = sh.search_batch(dQ, k, 1, with_positions=True)      # device queries: vl_shard_search_local_dev
+    assert cnt.tolist() == [k] * nq
+    hi, hs, hn, hp = sh.search_batch(Q, k, 1, with_positions=True)               # host queries: the same records
+    assert hi.tolist() == ids.tolist() and hs.tolist() == scores.tolist() and hp.tolist() == gpos.tolist()
+    # ties across shard boundaries come back in GLOBAL storage order
+    assert gpos[7, :4].tolist() == [per - 1, per, 5 * per + per // 2, n - 1] and scores[7, 0] == scores[7, 3] == 1.0
+    assert gpos[500, :2].tolist() == [3 * per - 1, 3 * per] and scores[500, 0] == scores[500, 1] == 1.0
+    assert ids[7, :4].tolist() == [int(ids_for(p, 1)[0]) for p in (per - 1, per, 5 * per + per // 2, n - 1)]
+    # the oracle on the union (rows copied back from the shards: exactly what they hold), 16 sampled queries + the two tie queries
+    rows = np.empty((n, dim))
+    for r, s in enumerate(shards):
+        _, vals = s.export()
+        rows[r * per:(r + 1) * per] = vals
+    ref = O.FlatOracle(dim, ids_for(0, n), rows)
+    for qi in [7, 500] + list(range(0, nq, 73)):
+        ri, rs = ref.search(Q[qi], k, 1)
+        assert ids[qi].tolist() == ri.tolist() and scores[qi].tolist() == rs.tolist(), qi
+
+
+def test_config3_10m_x_768_as_8_row_shards_on_one_card_equals_one_unsharded_index(V):
+    import gc
+    import torch
+    from vectorlite_amd.sharded import OneProcessShards
+    n, dim, nq, k, world = 10_000_000, 768, 1024, 10, 8
+    per = n // world
+    plant, t1, t2 = _tie_plan(np.random.default_rng(32), n, world, dim)
+    make_unsharded, make_shards = _build_unsharded_and_shards(V, n, dim, world, seed=900, chunk=250_000, plant=plant)
+    Q = unit_rows(np.random.default_rng(4321), nq, dim)
+    Q[7], Q[500] = t1, t2
+    dQ = torch.from_numpy(Q).to("cuda:0")
+    # (1) ONE index holding all 10 M rows: the answer the shards must reproduce
+    one = make_unsharded()
+    assert len(one) == n
+    wp, wi, ws, wn = one.search_batch_device(dQ, k, 1, with_positions=True)
+    assert wn.tolist() == [k] * nq
+    for qi in (0, 7, 500, 1023):              # ... which is itself the single-search answer
+        sp, si, ss = one.search_positions(Q[qi], k, 1)
+        assert wi[qi].tolist() == si.tolist() and ws[qi].tolist() == ss.tolist() and wp[qi].tolist() == sp.tolist(), qi
+    want = (wi.copy(), ws.copy(), wp.copy())
+    del one
+    gc.collect()
+    torch.cuda.empty_cache()
+    # (2) the same rows as 8 shards of 1.25 M on the same card, through the two halves of vl_shard_search_batch
+    shards = make_shards()
+    sh = OneProcessShards(shards)
+    assert sh.total == n and sh.max_len == per
+    t = {}
+    ids, scores, cnt, gpos = sh.search_batch(dQ, k, 1, with_positions=True, timings=t)
+    assert cnt.tolist() == [k] * nq
+    assert ids.tolist() == want[0].tolist()
+    assert scores.tolist() == want[1].tolist()          # f64, bit for bit
+    assert gpos.tolist() == want[2].tolist()            # global position = shard offset + local position
+    assert gpos[7, :4].tolist() == [per - 1, per, 5 * per + per // 2, n - 1]
+    assert gpos[500, :2].tolist() == [3 * per - 1, 3 * per]
+    ids2, scores2, cnt2 = sh.search_batch(dQ, k, 1, timings=t)   # a second, warm pass: the timing worth printing
+    assert ids2.tolist() == ids.tolist() and scores2.tolist() == scores.tolist()
+    print("config 3 at full size on one card: per-shard ms", [round(x, 2) for x in t["local_ms"]], "merge ms", round(t["merge_ms"], 3))

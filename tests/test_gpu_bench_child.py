@@ -59,7 +59,7 @@ def test_bench_child_process_prints_the_whole_contract_line(steps, warmup):
     sus = out["value_sustained"]
     assert sus["queries"] >= 64 and sus["value"] > 0 and sus["k_scan_avg_launch_ms"] > 0
     oc = out["config"]["other_configs"]
-    assert set(oc) == {"c2", "c5", "c3_shard", "c4_hnsw"}
+    assert set(oc) == {"c2", "c5", "c3_shard", "c3_full_one_card", "c4_hnsw"}
     assert oc["c2"]["roofline"]["bound"] == "hbm" and 0 < oc["c2"]["roofline"]["frac"] < 1 and oc["c2"]["fast_vs_exact"].startswith("4/4")
     assert oc["c5"]["roofline"]["bound"] == "mfma" and oc["c5"]["roofline"]["frac"] > 0
     assert oc["c5"]["rows_identical_to_single_search"].startswith("16/16")
@@ -73,6 +73,14 @@ def test_bench_child_process_prints_the_whole_contract_line(steps, warmup):
     # the same batch taken from device memory (vl_shard_search_batch_dev): timed beside the host form, identical answer
     assert c3["device_queries"]["identical_to_host_queries"] is True and c3["device_queries"]["ms_per_batch"] > 0
     assert c3["ms_per_batch"] == c3["device_queries"]["ms_per_batch"] and c3["host_queries_pcie_inclusive"]["ms_per_batch"] > 0
+    # config 3 at its own shape: every shard of the corpus on this card, the two halves of vl_shard_search_batch around the merge
+    cf = oc["c3_full_one_card"]
+    assert cf["shards"] == 8 and cf["rows_per_shard"] == [20000] * 8 and cf["ms_per_batch_per_shard"] > 0 and cf["merge_ms_for_all_records"] > 0
+    assert cf["second_pass_identical"] is True and cf["scores_sorted"] is True and cf["every_shards_rows_match_its_own_single_search"] == "4/4"
+    assert out["nccl_ranks_seen"] == 1 and c3["nccl_ranks_seen"] == 1     # what RCCL's communicator itself reports (vl_comm_world)
+    cc = out["concurrent_16_threads"]
+    assert cc["threads"] == 16 and cc["identical_to_lone_search"] == "16/16" and cc["value"] > 0
+    assert cc["passes"] <= cc["queries"] and cc["latency_ms"]["p99"] >= cc["latency_ms"]["p50"] > 0
     c4 = oc["c4_hnsw"]
     assert c4["parity"].startswith("unpinned") and set(c4["data"]) == {"latent16", "iid_gaussian"}
     for dist_name in ("latent16", "iid_gaussian"):

@@ -29,7 +29,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["ShardedFlatIndex", "Comm", "shard_ranges", "pack_words", "unpack_record"]
+__all__ = ["ShardedFlatIndex", "OneProcessShards", "Comm", "shard_ranges", "pack_words", "unpack_record"]
 
 VL_COMM_ID_BYTES = 128
 SHARD_HDR_WORDS = 4
@@ -259,3 +259,78 @@ class ShardedFlatIndex:
         ids, scores, n = self.search_batch(np.asarray(query, dtype=np.float64)[None, :], k, metric)
         m = int(n[0])
         return ids[0, :m].copy(), scores[0, :m].copy()
+
+
+class OneProcessShards:
+    """The row shards of one corpus as separate flat handles in ONE process (one card, or several): a batch is answered by
+    vl_shard_search_local(_dev) on every shard and ONE vl_shard_merge over the `world` records -- exactly the calls an
+    N-rank run makes (ShardedFlatIndex, transport "torch"), minus the wire.  BASELINE config 3 at its own size runs through
+    this on a single MI355X (8 shards of 1.25 M x 768 fit one card: 107 GB with the bf16 copies); the answer is bit-identical
+    to one index holding every row in shard order (src/index/flat.rs:98-119 on the union)."""
+
+    def __init__(self, shards, merge_device: int = None):
+        if not shards:
+            raise ValueError("at least one shard")
+        self._L = _lib.load()
+        self.shards = list(shards)
+        self.world = len(self.shards)
+        dims = {s.dimension() for s in self.shards}
+        if len(dims) != 1:
+            raise ValueError(f"shards disagree on the dimension: {sorted(dims)}")
+        self.merge_device = int(self.shards[0].device if merge_device is None else merge_device)
+        self.sync()
+
+    def sync(self) -> int:
+        """Re-read the shard lengths (after add / delete on any shard).  Returns the total row count."""
+        lens = [len(s) for s in self.shards]
+        self.offsets = [int(x) for x in np.concatenate([[0], np.cumsum(lens)[:-1]])]
+        self.total = int(sum(lens))
+        self.max_len = int(max(lens))
+        return self.total
+
+    def search_batch(self, queries, k: int, metric: int = 0, with_positions: bool = False, timings: dict = None):
+        """(ids [nq, k'], scores [nq, k'], n [nq]) with k' = min(k, total rows) (+ global positions on request).
+        timings (optional dict): receives 'local_ms' (per shard, host clock around the shard's call) and 'merge_ms'."""
+        import time
+        from . import _raise
+        on_device = _is_device_tensor(queries)
+        if on_device:
+            import torch
+            if queries.dtype != torch.float64 or not queries.is_contiguous() or queries.dim() != 2:
+                raise ValueError("device queries must be a contiguous float64 [nq, dim] tensor")
+            torch.cuda.current_stream(queries.device).synchronize()
+            nq, qlen = int(queries.shape[0]), int(queries.shape[1])
+            qptr = C.c_void_p(queries.data_ptr())
+        else:
+            Q = np.ascontiguousarray(np.asarray(queries, dtype=np.float64))
+            if Q.ndim == 1:
+                Q = Q[None, :]
+            nq, qlen = Q.shape
+        k = int(k)
+        kk = max(min(k, max(self.total, 1)), 1)
+        k_call = min(k, kk)
+        ids = np.zeros((nq, kk), dtype=np.uint64)
+        gpos = np.zeros((nq, kk), dtype=np.uint64)
+        scores = np.zeros((nq, kk), dtype=np.float64)
+        n = np.zeros(max(nq, 1), dtype=np.uint64)
+        if k_call > 0 and self.total > 0 and nq > 0:
+            ks = min(k_call, self.max_len)
+            gathered = np.zeros((self.world, pack_words(nq, ks)), dtype=np.uint64)
+            local_ms = []
+            for r, s in enumerate(self.shards):
+                t0 = time.perf_counter()
+                if on_device:
+                    _raise(self._L.vl_shard_search_local_dev(s._h, self.offsets[r], 1, qptr, nq, qlen, ks, int(metric),
+                                                             _pu64(gathered[r])))
+                else:
+                    _raise(self._L.vl_shard_search_local(s._h, self.offsets[r], 1, _pf64(Q), nq, qlen, ks, int(metric),
+                                                         _pu64(gathered[r])))
+                local_ms.append((time.perf_counter() - t0) * 1e3)
+            t0 = time.perf_counter()
+            _raise(self._L.vl_shard_merge(self.merge_device, _pu64(gathered), self.world, nq, ks, k_call, _pu64(gpos), _pu64(ids),
+                                          _pf64(scores), _pu64(n)))
+            if timings is not None:
+                timings["local_ms"] = local_ms
+                timings["merge_ms"] = (time.perf_counter() - t0) * 1e3
+        out = (ids[:, :k_call], scores[:, :k_call], n[:nq])
+        return out + (gpos[:, :k_call],) if with_positions else out
