@@ -317,6 +317,12 @@ int vl_comm_profile_enable(vl_comm *comm, int enable);
 int vl_comm_profile_read(vl_comm *comm, uint64_t *calls, double *local_ms, double *h2d_ms, double *allgather_ms,
                          double *merge_ms);
 
+/* How this rank's exchange records were made, since the communicator was created: on_device = batches whose record the
+ * finalize kernel wrote straight into the all-gather's send buffer (only the 32-byte header then crosses PCIe in front of
+ * the collective; round 4), via_host = batches that built it in pinned host memory and copied it over (Manhattan, tiny
+ * shards, k > 60, failures travelling in word 0).  Either pointer may be NULL. */
+int vl_comm_record_paths(const vl_comm *comm, uint64_t *on_device, uint64_t *via_host);
+
 /* Collective: the ranks exchange (len, dimension) of their shards; each learns the global position of its
  * first row (*out_offset, rank order) and the total row count.  Call after building the shards and again
  * after any add/delete on any of them; a shard that changed since is reported as VL_ERR_INVALID_ARG by the

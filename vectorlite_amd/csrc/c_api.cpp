@@ -2,8 +2,11 @@
 // No C++ exception crosses it: every entry point catches and maps to a vl_status.
 #include "../../include/vectorlite_amd.h"
 
+#include <memory>
+#include <mutex>
 #include <new>
 #include <stdexcept>
+#include <vector>
 
 #include "flat_index.hpp"
 #include "hnsw_index.hpp"
@@ -490,6 +493,13 @@ int vl_comm_profile_read(vl_comm* comm, uint64_t* calls, double* local_ms, doubl
     return VL_OK;
 }
 
+int vl_comm_record_paths(const vl_comm* comm, uint64_t* on_device, uint64_t* via_host)
+{
+    if (!comm || !comm->c) return VL_ERR_INVALID_ARG;
+    comm->c->record_paths(on_device, via_host);
+    return VL_OK;
+}
+
 int vl_shard_sync(const vl_index* shard, vl_comm* comm, uint64_t* out_offset, uint64_t* out_total)
 {
     return guarded([&]() -> int {
@@ -547,6 +557,21 @@ int vl_shard_search_local_dev(const vl_index* shard, uint64_t row_offset, int co
     });
 }
 
+namespace {
+std::mutex& merger_pool_mu()
+{
+    static std::mutex mu;
+    return mu;
+}
+std::vector<std::unique_ptr<vl::ShardMerger>>& merger_pool()
+{
+    // idle mergers of vl_shard_merge, any device, at most 8; never destroyed (a static destructor would call hipFree after
+    // the HIP runtime has been torn down at process exit)
+    static auto* pool = new std::vector<std::unique_ptr<vl::ShardMerger>>();
+    return *pool;
+}
+}  // namespace
+
 int vl_shard_merge(int device, const uint64_t* gathered, uint32_t world, uint64_t nq, uint64_t ks, uint64_t k,
                    uint64_t* out_gpos, uint64_t* out_ids, double* out_scores, uint64_t* out_n)
 {
@@ -564,9 +589,31 @@ int vl_shard_merge(int device, const uint64_t* gathered, uint32_t world, uint64_
             vl::set_last_error("no usable HIP device (vectorlite_amd has no CPU fallback)");
             return VL_ERR_DEVICE;
         }
-        vl::ShardMerger m(device);  // buffers per call: this is the bring-your-own-transport path
-        return m.merge_host(reinterpret_cast<const unsigned long long*>(gathered), world, nq, ks, k, out_gpos, out_ids,
-                            out_scores, out_n);
+        // the bring-your-own-transport path: mergers (a stream, the gathered-records / output buffers) are kept per device
+        // and lent to one call at a time -- making them per call cost ~0.9 ms of allocations against a 25 us merge kernel
+        struct Lease {
+            std::unique_ptr<vl::ShardMerger> m;
+            ~Lease()
+            {
+                if (!m) return;
+                std::lock_guard<std::mutex> g(merger_pool_mu());
+                auto& pool = merger_pool();
+                if (pool.size() < 8) pool.push_back(std::move(m));
+            }
+        } lease;
+        {
+            std::lock_guard<std::mutex> g(merger_pool_mu());
+            auto& pool = merger_pool();
+            for (size_t i = 0; i < pool.size(); ++i)
+                if (pool[i]->device() == device) {
+                    lease.m = std::move(pool[i]);
+                    pool.erase(pool.begin() + (long)i);
+                    break;
+                }
+        }
+        if (!lease.m) lease.m.reset(new vl::ShardMerger(device));
+        return lease.m->merge_host(reinterpret_cast<const unsigned long long*>(gathered), world, nq, ks, k, out_gpos, out_ids,
+                                   out_scores, out_n);
     });
 }
 

@@ -6,6 +6,7 @@
 // positions back to ids for the k winners (the reference re-attaches text/metadata the same way,
 // src/index/flat.rs:106-114).  There is no CPU compute fallback.
 #include "flat_index.hpp"
+#include "shard.hpp"
 
 #include <chrono>
 
@@ -240,7 +241,7 @@ GpuFlatIndex::~GpuFlatIndex()
     (void)hipSetDevice(device_);
     if (ws_pool_) detach_pool(device_, dim_);
     if (mut_stream_) (void)hipStreamSynchronize(mut_stream_);
-    void* dev[] = {d_master_, d_slab_, d_inv_norm_, d_flags_, d_stats_, d_bounce_, d_slab16_, d_sqnorm_, d_norm16_, d_slab16f_};
+    void* dev[] = {d_master_, d_slab_, d_inv_norm_, d_flags_, d_stats_, d_bounce_, d_slab16_, d_sqnorm_, d_norm16_, d_slab16f_, d_ids_};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     if (mut_stream_) (void)hipStreamDestroy(mut_stream_);
@@ -270,6 +271,7 @@ void GpuFlatIndex::truncate(uint64_t n_rows)
     id_counts_valid_ = false;  // rebuilt on demand from ids_
     if (slab16_rows_ > n_rows) slab16_rows_ = n_rows;
     if (slab16f_rows_ > n_rows) slab16f_rows_ = n_rows;
+    if (d_ids_rows_ > n_rows) d_ids_rows_ = n_rows;
 }
 
 int GpuFlatIndex::ensure_capacity(uint64_t rows)
@@ -464,6 +466,7 @@ int GpuFlatIndex::remove_position(uint64_t pos)
     if (row_flags_[pos] & ROW_OUT_OF_DOMAIN) --n_out_of_domain_;
     if (slab16_rows_ > pos) slab16_rows_ = pos;  // rows behind the hole are re-converted on demand
     if (slab16f_rows_ > pos) slab16f_rows_ = pos;
+    if (d_ids_rows_ > pos) d_ids_rows_ = pos;    // ... and the device id table re-uploaded from there
     ids_.erase(ids_.begin() + pos);
     row_flags_.erase(row_flags_.begin() + pos);
     return OK;
@@ -1222,6 +1225,123 @@ int GpuFlatIndex::ensure_bf16_slab(bool frag_major) const
     return OK;
 }
 
+// position -> id on the device, for exchange records written by the finalize kernel (search_batch_to_record).  Caller holds
+// mu_ (shared or unique); concurrent callers serialise on bf16_mu_ like the other lazily built device copies.
+int GpuFlatIndex::ensure_device_ids() const
+{
+    std::lock_guard<std::mutex> g(bf16_mu_);
+    const uint64_t n = ids_.size();
+    if (d_ids_cap_ < n) {
+        unsigned long long* fresh = nullptr;
+        const uint64_t want = std::max<uint64_t>(cap_, n);
+        VL_HIP(hipMalloc(reinterpret_cast<void**>(&fresh), want * sizeof(unsigned long long)));
+        if (d_ids_) (void)hipFree(d_ids_);
+        d_ids_ = fresh;
+        d_ids_cap_ = want;
+        d_ids_rows_ = 0;
+    }
+    if (d_ids_rows_ < n) {
+        static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64 ids");
+        VL_HIP(hipMemcpyAsync(d_ids_ + d_ids_rows_, ids_.data() + d_ids_rows_, (n - d_ids_rows_) * sizeof(uint64_t),
+                              hipMemcpyHostToDevice, mut_stream_));
+        VL_HIP(hipStreamSynchronize(mut_stream_));
+        d_ids_rows_ = n;
+    }
+    return OK;
+}
+
+int GpuFlatIndex::search_batch_to_record(const double* queries, bool queries_on_device, uint64_t nq, uint64_t q_len, uint64_t ks,
+                                         int metric, uint64_t row_offset, unsigned long long* d_record, bool* handled) const
+{
+    if (handled) *handled = false;
+    if (!handled || !d_record || nq == 0 || ks == 0 || !queries || metric < 0 || metric > 3) return OK;  // the host path decides
+    VL_HIP(hipSetDevice(device_));
+    std::shared_lock<RwLock> lk(mu_);
+    const uint64_t n = ids_.size();
+    if (n == 0 || q_len != dim_) return OK;  // (errors and empty shards are the host path's to report)
+    const uint64_t k_eff = std::min<uint64_t>(ks, n);
+    const char* mf_env = getenv("VL_MFMA");
+    const char* mf_min = getenv("VL_MFMA_MIN_BATCH");
+    const uint64_t mfma_min = mf_min && *mf_min ? (uint64_t)atoi(mf_min) : (uint64_t)MFMA_MIN_BATCH;
+    const bool direct = nq > 1 && force_path_.load() == 0 && k_eff <= (uint64_t)KFAST_MAX && n_out_of_domain_ == 0 &&
+                        !(mf_env && mf_env[0] == '0') && nq >= mfma_min && n >= MFMA_MIN_ROWS &&
+                        mfma_scan_supported((uint32_t)dim_, metric) && nq * ks < (1ull << 31);
+    if (!direct) return OK;
+    VL_TRY(ensure_device_ids());
+    ShardRecordSink sink;
+    sink.cnt = d_record + SHARD_HDR_WORDS;
+    sink.score_bits = sink.cnt + nq;
+    sink.gpos = sink.score_bits + nq * ks;
+    sink.ids = sink.gpos + nq * ks;
+    sink.pos_to_id = d_ids_;
+    sink.row_offset = row_offset;
+    sink.ks = (uint32_t)ks;
+    // host-side answers of the queries the filter certifies are not needed (the record is the answer); the others come back
+    // through `done` and are redone below
+    std::vector<uint8_t> done(nq, 0);
+    std::vector<uint64_t> cnt(nq, 0);
+    std::vector<uint64_t> pos, ids;
+    std::vector<double> sc;
+    try {
+        pos.resize(nq * ks);
+        ids.resize(nq * ks);
+        sc.resize(nq * ks);
+    } catch (const std::bad_alloc&) {
+        set_last_error("out of host memory in the shard search");
+        return ERR_OOM;
+    }
+    {
+        Workspace* ws = acquire_ws();
+        if (!ws) return ERR_DEVICE;
+        struct Releaser {
+            const GpuFlatIndex* self;
+            Workspace* ws;
+            ~Releaser()
+            {
+                (void)hipStreamSynchronize(ws->stream);
+                self->release_ws(ws);
+            }
+        } rel{this, ws};
+        VL_TRY(search_batch_mfma(ws, queries_on_device ? nullptr : queries, queries_on_device ? queries : nullptr, nq, ks, k_eff, metric,
+                                 pos.data(), ids.data(), sc.data(), cnt.data(), &done, &sink));
+    }
+    set_last_path(PATH_FAST);
+    // what the filter could not certify: the host paths answer those queries (under the same shared lock: one index state
+    // for the whole batch) and their slices of the record are patched; typically none
+    std::vector<uint64_t> left;
+    for (uint64_t qi = 0; qi < nq; ++qi)
+        if (!done[qi]) left.push_back(qi);
+    if (!left.empty()) {
+        const uint64_t m = left.size();
+        std::vector<double> hq(m * dim_);
+        for (uint64_t i = 0; i < m; ++i) {
+            if (queries_on_device)
+                VL_HIP(hipMemcpy(hq.data() + i * dim_, queries + left[i] * dim_, dim_ * sizeof(double), hipMemcpyDeviceToHost));
+            else
+                std::memcpy(hq.data() + i * dim_, queries + left[i] * dim_, dim_ * sizeof(double));
+        }
+        std::vector<uint64_t> t_pos(m * ks), t_ids(m * ks), t_n(m, 0);
+        std::vector<double> t_sc(m * ks);
+        VL_TRY(search_batch_locked(hq.data(), m, dim_, ks, metric, t_pos.data(), t_ids.data(), t_sc.data(), t_n.data()));
+        for (uint64_t i = 0; i < m; ++i) {
+            const uint64_t qi = left[i], c = std::min<uint64_t>(t_n[i], ks);
+            std::vector<unsigned long long> buf(3 * ks, 0ull);
+            for (uint64_t j = 0; j < c; ++j) {
+                std::memcpy(&buf[j], &t_sc[i * ks + j], 8);
+                buf[ks + j] = t_pos[i * ks + j] + row_offset;
+                buf[2 * ks + j] = t_ids[i * ks + j];
+            }
+            const unsigned long long c64 = c;
+            VL_HIP(hipMemcpy(sink.cnt + qi, &c64, 8, hipMemcpyHostToDevice));
+            VL_HIP(hipMemcpy(sink.score_bits + qi * ks, buf.data(), ks * 8, hipMemcpyHostToDevice));
+            VL_HIP(hipMemcpy(sink.gpos + qi * ks, buf.data() + ks, ks * 8, hipMemcpyHostToDevice));
+            VL_HIP(hipMemcpy(sink.ids + qi * ks, buf.data() + 2 * ks, ks * 8, hipMemcpyHostToDevice));
+        }
+    }
+    *handled = true;
+    return OK;
+}
+
 int GpuFlatIndex::ensure_mfma_scratch(Workspace* ws) const
 {
     if (ws->mf.nq_cap) return OK;
@@ -1247,7 +1367,8 @@ int GpuFlatIndex::ensure_mfma_scratch(Workspace* ws) const
 // answered here; the caller redoes the others (bound check failed, candidate overflow, ...).
 int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, const double* d_queries, uint64_t nq,
                                     uint64_t k, uint64_t k_eff, int metric, uint64_t* out_pos, uint64_t* out_ids,
-                                    double* out_scores, uint64_t* out_n, std::vector<uint8_t>* done) const
+                                    double* out_scores, uint64_t* out_n, std::vector<uint8_t>* done,
+                                    const ShardRecordSink* sink) const
 {
     const uint64_t n = ids_.size();
     const bool frag = mfma_rows_kernel((uint32_t)dim_);  // which kernel, hence which slab layout
@@ -1291,9 +1412,14 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, const 
         VL_HIP(launch_mfma_candidates(st, metric, slab16, d_norm16_, d_sqnorm_, ws->mf_d_q64, g, n, (uint32_t)dim_,
                                       ws->mf, ws->mf_lists));
         if (prof) VL_HIP(hipEventRecord(ws->ev1, st));
+        ShardRecordSink seq_sink;
+        if (sink) {  // this sequence's queries sit at [q0, q0 + g) of the record
+            seq_sink = *sink;
+            seq_sink.q0 = (uint32_t)q0;
+        }
         VL_HIP(launch_merge_finalize(st, metric, ws->mf_lists, 1, (int)g, d_master_, ws->mf_d_q64,
                                      ws->mf_d_q64 + (size_t)g * dim_, (uint32_t)dim_, n, (uint32_t)k_eff, max_row_norm_,
-                                     ws->mf_h_result, in_extra));
+                                     ws->mf_h_result, in_extra, 0, sink ? &seq_sink : nullptr));
         const auto t_2 = now();
         VL_HIP(hipStreamSynchronize(st));
         if (d_queries)

@@ -145,6 +145,14 @@ public:
     // not serve (Manhattan, one query, small indexes, queries it cannot certify) is copied to the host and answered there.
     int search_batch_device(const double* d_queries, uint64_t nq, uint64_t q_len, uint64_t k, int metric, uint64_t* out_pos,
                             uint64_t* out_ids, double* out_scores, uint64_t* out_n) const;
+    // A row shard's answer written straight into the DEVICE planes of its exchange record (shard.hpp; `record` = the
+    // record's first word in this GPU's memory, stride ks = k): the finalize kernel fills count / score / global position /
+    // id of every query it certifies, the few it cannot are redone through the host paths and their slices patched.  Queries
+    // on the host (queries_on_device = false) or in this GPU's memory.  *handled = false (and nothing written): this batch
+    // does not take the MFMA filter (Manhattan, one query, a small or empty shard, out-of-domain rows, k > 60 ...) -- the
+    // caller then builds the record on the host as before.  Word 0..3 of the record (status, len, dim) are the caller's.
+    int search_batch_to_record(const double* queries, bool queries_on_device, uint64_t nq, uint64_t q_len, uint64_t ks,
+                               int metric, uint64_t row_offset, unsigned long long* d_record, bool* handled) const;
     uint64_t len() const;
     bool is_empty() const { return len() == 0; }
     uint64_t dimension() const { return dim_; }
@@ -217,7 +225,9 @@ private:
                             uint64_t* out_ids, double* out_scores, uint64_t* out_n) const;  // mu_ held (shared)
     int search_batch_mfma(Workspace* ws, const double* queries, const double* d_queries, uint64_t nq, uint64_t k,
                           uint64_t k_eff, int metric, uint64_t* out_pos, uint64_t* out_ids, double* out_scores,
-                          uint64_t* out_n, std::vector<uint8_t>* done) const;  // queries on the host, or d_queries on the device
+                          uint64_t* out_n, std::vector<uint8_t>* done,
+                          const ShardRecordSink* sink = nullptr) const;  // queries on the host, or d_queries on the device
+    int ensure_device_ids() const;  // lazily uploads the position -> id table (what a device-written exchange record needs)
 
     const uint64_t dim_;
     const uint32_t ld_;  // slab row stride in floats: dim rounded up to 4 (16-byte vector loads)
@@ -236,6 +246,8 @@ private:
     mutable void* d_slab16f_ = nullptr;    // the same rows in MFMA fragment order: what k_mfma_rows streams (lazy; dims <= 384)
     mutable uint64_t slab16f_rows_ = 0;
     mutable std::mutex bf16_mu_;
+    mutable unsigned long long* d_ids_ = nullptr;  // [d_ids_cap_] position -> id on the device (lazy: row-sharded batches only)
+    mutable uint64_t d_ids_cap_ = 0, d_ids_rows_ = 0;  // rows uploaded so far (a delete rewinds it like the bf16 copies)
     IngestStats* d_stats_ = nullptr;
     uint64_t cap_ = 0;  // rows every array holds (the minimum of the four below)
     uint64_t cap_master_ = 0, cap_slab_ = 0, cap_inv_ = 0, cap_flags_ = 0;

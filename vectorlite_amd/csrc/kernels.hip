@@ -586,7 +586,7 @@ __global__ __launch_bounds__(1024) void k_merge_finalize(const Cand32* __restric
                                                          const double* __restrict__ q_norms, uint32_t dim,
                                                          uint32_t ld, uint64_t n_rows, uint32_t k, double R,
                                                          double in_extra, SearchResultBlock* __restrict__ out,
-                                                         uint32_t seq)
+                                                         uint32_t seq, ShardRecordSink sink)
 {
     // one workgroup per query of the batch
     partials += (size_t)blockIdx.x * list_stride_q;
@@ -677,6 +677,17 @@ __global__ __launch_bounds__(1024) void k_merge_finalize(const Cand32* __restric
         if (lane == 0) {
             out->n_out = k_eff;
             out->flags = flags;
+        }
+        if (sink.cnt) {  // a row shard's exchange record, written where the all-gather reads it (shard.hpp)
+            const uint32_t q = sink.q0 + blockIdx.x;
+            const uint32_t offered = (flags == 0u) ? (k_eff < sink.ks ? k_eff : sink.ks) : 0u;  // not certified: the host redoes it
+            if (valid && (uint32_t)rank < offered) {
+                const size_t e = (size_t)q * sink.ks + (uint32_t)rank;
+                sink.score_bits[e] = (unsigned long long)__double_as_longlong(sc);
+                sink.gpos[e] = sink.row_offset + (unsigned long long)my_pos;
+                sink.ids[e] = sink.pos_to_id[my_pos];
+            }
+            if (lane == 0) sink.cnt[q] = offered;
         }
         VL_STAMP(9);
         if (seq) {
@@ -1507,16 +1518,17 @@ const C* reduce_lists(hipStream_t s, const C* lists, int* n_lists, size_t* strid
 hipError_t launch_merge_finalize(hipStream_t s, int metric, Cand32* partials, int n_lists, int nq,
                                  const double* master, const double* q64, const double* q_norms, uint32_t dim,
                                  uint64_t n_rows, uint32_t k, double max_row_norm, SearchResultBlock* out,
-                                 double in_extra, uint32_t seq)
+                                 double in_extra, uint32_t seq, const ShardRecordSink* sink)
 {
     if (seq && nq != 1) return hipErrorInvalidValue;
+    const ShardRecordSink sk = sink ? *sink : ShardRecordSink{};
     const uint32_t ld = (dim + 3u) & ~3u;
     size_t stride = (size_t)n_lists * KP;
     const Cand32* lists = reduce_lists<float, Cand32>(s, partials, &n_lists, &stride, nq, partials + PARTIALS32_LISTS * KP);
     return dispatch_metric(metric, [&](auto M) -> hipError_t {
         constexpr int MM = decltype(M)::value;
         hipLaunchKernelGGL((k_merge_finalize<MM>), dim3(nq), dim3(1024), 0, s, lists, n_lists, stride, master, q64,
-                           q_norms, dim, ld, n_rows, k, max_row_norm, in_extra, out, seq);
+                           q_norms, dim, ld, n_rows, k, max_row_norm, in_extra, out, seq, sk);
         return hipGetLastError();
     });
 }

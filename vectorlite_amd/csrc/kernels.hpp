@@ -44,6 +44,21 @@ struct SearchResultBlock {
 constexpr uint32_t RESULT_NEEDS_EXACT = 1u;  // bound check failed / tie at the cut: redo on the exact path
 constexpr uint32_t RESULT_HAS_NAN = 2u;      // some score is NaN
 
+// Device planes of a row shard's exchange record (shard.hpp) that the finalize kernel fills directly, so that the record of a
+// batch never visits the host on its way into the all-gather: for query q (q0 + block index) the certified answer's
+// (score bits, shard offset + position, id) at [q * ks + rank], and cnt[q] = entries offered -- 0 when the bound check did
+// not certify the answer (the host redoes that query and patches its slice of the record).  cnt == nullptr: no record.
+struct ShardRecordSink {
+    unsigned long long* cnt = nullptr;         // [nq]
+    unsigned long long* score_bits = nullptr;  // [nq, ks]
+    unsigned long long* gpos = nullptr;        // [nq, ks]
+    unsigned long long* ids = nullptr;         // [nq, ks]
+    const unsigned long long* pos_to_id = nullptr;  // [n_rows] this shard's position -> id table on the device
+    unsigned long long row_offset = 0;         // global position of the shard's first row
+    uint32_t ks = 0;                           // record row stride
+    uint32_t q0 = 0;                           // first query of this launch within the record
+};
+
 // Per-index device statistics maintained by the ingest kernel.
 struct IngestStats {
     unsigned long long max_norm_bits;  // bits of the largest row L2 norm (f64, >= 0)
@@ -107,7 +122,7 @@ hipError_t launch_merge_finalize_multi(hipStream_t s, int metric, Cand32* partia
 hipError_t launch_merge_finalize(hipStream_t s, int metric, Cand32* partials, int n_lists, int nq,
                                  const double* master, const double* q64, const double* q_norms, uint32_t dim,
                                  uint64_t n_rows, uint32_t k, double max_row_norm, SearchResultBlock* out,
-                                 double in_extra = 0.0, uint32_t seq = 0);
+                                 double in_extra = 0.0, uint32_t seq = 0, const ShardRecordSink* sink = nullptr);
 
 // K3: one slab pass for nq <= SCAN_BATCH_QB queries (q64 is [nq, dim]); lists are written query-major.
 bool scan_batch_supported(uint32_t ld);

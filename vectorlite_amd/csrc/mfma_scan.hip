@@ -523,8 +523,16 @@ constexpr int rs_qpb(uint32_t ldb) { return ldb <= 384 ? 32 * RS_HQB1 : (ldb <= 
 constexpr int rs_seg(uint32_t ldb) { return (size_t)rs_qpb(ldb) * (ldb * 2 + 32) + 8 * 192 * 10 + 1024 <= 160 * 1024 ? 192 : 128; }
 
 
-template <int KSTEPS, int MODE, int METRIC>
-__global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __restrict__ slab16,
+// Two shapes of the same kernel (round 4):
+//   RBN = 2, NW = 8  two waves per SIMD, 32-row wave blocks (rounds 2-3; still the sampling pass, MODE 0);
+//   RBN = 4, NW = 4  ONE wave per SIMD with the whole 512-register file (accumulators spill over into the AccVGPRs),
+//                    64-row wave blocks, every query block of the workgroup in one sub-iteration (4 x 8 wave tile at
+//                    strides <= 512, 4 x 6 at 768), K walked in phases of <= 6 K-steps with the row fragments refilled
+//                    in place: each ds_read_b128 of a query fragment feeds 4 MFMAs instead of 2 (half the LDS bytes per
+//                    flop), and nothing is duplicated between two waves that ran in lockstep anyway.
+template <int KSTEPS, int MODE, int METRIC, int RBN = 2, int NW = RS_NWAVES>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, (NW == 4 ? 1 : 2))))
+void k_mfma_rows(const __bf16* __restrict__ slab16,
                                                               const float* __restrict__ row_nrm,
                                                               const float* __restrict__ row_sqn,
                                                               const __bf16* __restrict__ q16, uint32_t nq,
@@ -537,14 +545,19 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     constexpr int ROW_BYTES = LDB * 2;
     constexpr int LDS_ROW = ROW_BYTES + 32;   // same padding as k_mfma_scan's row tiles: conflict-free ds_read_b128
     constexpr int KS32 = KSTEPS / 2;          // K = 32 per MFMA
-    constexpr int NT = RS_NWAVES * 64;
+    constexpr int NT = NW * 64;
+    constexpr int BR = 16 * RBN;              // rows per wave block
+    static_assert((RBN == 2 && NW == 8) || (RBN == 4 && NW == 4), "two waves per SIMD on 32-row blocks, or one on 64-row blocks");
+    static_assert(BR <= (int)MFMA_TILE_ROWS, "the slab is allocated in whole tiles of MFMA_TILE_ROWS rows");
     // A row block is worked off in NU sub-iterations that all reuse the KSP row fragments a wave holds:
-    //   dims <= 384: the whole K stays in registers (PH = 1) and the 128 queries come in QH = 2 halves of 4 query blocks;
-    //   dim 768:     K comes in PH phases of KSP K-steps (the fragment registers are refilled for the next phase while
-    //                one runs), the accumulators live through all of them, 16 RS_HQB768 queries (QH = 1).
-    constexpr int PH = (KSTEPS > 32) ? RS_PH768 : 1;
-    constexpr int QH = (PH == 1) ? 2 : 1;
-    constexpr int HQB = (PH > 1) ? RS_HQB768 : (LDB <= 384 ? RS_HQB1 : 4);  // query blocks (of 16) per sub-iteration
+    //   RBN = 2, dims <= 384: the whole K stays in registers (PH = 1) and the 128 queries come in QH = 2 halves of 4 query blocks;
+    //   RBN = 2, dim 768:     K comes in PH phases of KSP K-steps (the fragment registers are refilled for the next phase while
+    //                         one runs), the accumulators live through all of them, 16 RS_HQB768 queries (QH = 1);
+    //   RBN = 4:              always phases (QH = 1: every query block of the workgroup at once), KSP = 6 K-steps where 6 divides
+    //                         the row (strides 384, 768), else 4.
+    constexpr int PH = (RBN == 4) ? ((KS32 % 6 == 0) ? KS32 / 6 : (KS32 > 4 ? KS32 / 4 : 1)) : ((KSTEPS > 32) ? RS_PH768 : 1);
+    constexpr int QH = (RBN == 4) ? 1 : ((PH == 1) ? 2 : 1);
+    constexpr int HQB = (RBN == 4) ? rs_qpb(LDB) / 16 : ((PH > 1) ? RS_HQB768 : (LDB <= 384 ? RS_HQB1 : 4));  // query blocks (of 16) per sub-iteration
     constexpr int QPB = QH * HQB * 16;        // queries per workgroup
     constexpr int QB = QPB / 16;
     constexpr int KSP = KS32 / PH;            // K-steps per phase = row fragments held per 16-row block
@@ -563,8 +576,9 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     constexpr int NB = B_AHEAD + 1;
     static_assert(NPOS % NB == 0, "the fragment-buffer rotation closes over one row block");
     static_assert(KSTEPS % 2 == 0, "whole 32-deep K steps");
-    constexpr int RS_SEG = rs_seg(LDB);
-    constexpr int RING = (MODE == 1) ? RS_NWAVES * RS_SEG : 1;
+    constexpr int RS_SEG = (NW == 4) ? 2 * rs_seg(LDB) : rs_seg(LDB);  // the ring's LDS is shared out over half as many waves
+    static_assert(NPOS % 2 == 0, "two query-fragment buffers rotate over a row block");
+    constexpr int RING = (MODE == 1) ? NW * RS_SEG : 1;
 
     __shared__ __attribute__((aligned(16))) unsigned char q_lds[QPB * LDS_ROW];
     __shared__ float ring_key[RING];
@@ -572,7 +586,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     __shared__ unsigned short ring_q[RING];
     // MODE 0: a workgroup reports gpw groups (1, 2, 4 or 8: its waves in equal shares), so that the sampling pass can run
     // on the same full-chip grid as pass 1 whatever the number of query chunks and still hand k_thresholds 64..256 groups
-    __shared__ int gmax_lds[MODE == 0 ? RS_NWAVES * QPB : 1];
+    __shared__ int gmax_lds[MODE == 0 ? NW * QPB : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -601,7 +615,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
             *reinterpret_cast<u32x4*>(&q_lds[r * LDS_ROW + cc * 16]) = *reinterpret_cast<const u32x4*>(src + (size_t)c * 16);
         }
         if (MODE == 0)
-            for (int c = tid; c < RS_NWAVES * QPB; c += NT) gmax_lds[c] = enc_f(-INFINITY);
+            for (int c = tid; c < NW * QPB; c += NT) gmax_lds[c] = enc_f(-INFINITY);
     }
     __syncthreads();
 
@@ -618,13 +632,13 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     }
     uint32_t my_cnt = 0;
 
-    // block schedule: neighbouring WORKGROUPS stream neighbouring 32-row blocks (block = begin + x + gridDim.x * (wave + 8 i)),
+    // block schedule: neighbouring WORKGROUPS stream neighbouring BR-row blocks (block = begin + x + gridDim.x * (wave + NW i)),
     // so in MODE 0 every workgroup (= group) owns rows as soon as there are gridDim.x blocks
 #ifdef RS_DBG_PAIRLOAD  // diagnostic: waves w and w + 4 (SIMD partners) stream the SAME blocks -- do their loads share L1?
-    const uint32_t stride = gridDim.x * (RS_NWAVES / 2);
+    const uint32_t stride = gridDim.x * (NW / 2);
     uint32_t b = blk_begin + bx + gridDim.x * (uint32_t)(wave & 3);
 #else
-    const uint32_t stride = gridDim.x * RS_NWAVES;
+    const uint32_t stride = gridDim.x * NW;
     uint32_t b = blk_begin + bx + gridDim.x * (uint32_t)wave;
 #endif
     const bool has_work = b < blk_end;
@@ -636,17 +650,21 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     // lines; at 128 queries per workgroup the L2 request rate, not the matrix pipe, then set the pace.)
     const uint32_t lane_off = (uint32_t)lane * 16u;
 #ifdef RS_DBG_HOTLOAD  // diagnostic: every load hits L2 (the waves re-read the same RS_DBG_HOTLOAD blocks): what do the MISSES cost?
-    auto a_ptr = [&](uint32_t blk) { return reinterpret_cast<const unsigned char*>(slab16) + (size_t)(blk % (uint32_t)(RS_DBG_HOTLOAD)) * (32 * ROW_BYTES) + lane_off; };
+    auto a_ptr = [&](uint32_t blk) { return reinterpret_cast<const unsigned char*>(slab16) + (size_t)(blk % (uint32_t)(RS_DBG_HOTLOAD)) * (BR * ROW_BYTES) + lane_off; };
 #else
-    auto a_ptr = [&](uint32_t blk) { return reinterpret_cast<const unsigned char*>(slab16) + (size_t)blk * (32 * ROW_BYTES) + lane_off; };
+    auto a_ptr = [&](uint32_t blk) { return reinterpret_cast<const unsigned char*>(slab16) + (size_t)blk * (BR * ROW_BYTES) + lane_off; };
 #endif
-    bf16x8 afrag[2][KSP];
-    f32x4 aux[2] = {f32x4{1.f, 1.f, 1.f, 1.f}, f32x4{1.f, 1.f, 1.f, 1.f}};
-    f32x4 aux2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    bf16x8 afrag[RBN][KSP];
+    f32x4 aux[RBN], aux2[RBN];
+#pragma unroll
+    for (int rb = 0; rb < RBN; ++rb) {
+        aux[rb] = f32x4{1.f, 1.f, 1.f, 1.f};
+        aux2[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     auto load_aux = [&](uint32_t blk) {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const uint32_t r0 = blk * 32 + 16 * rb + 4 * kg;
+        for (int rb = 0; rb < RBN; ++rb) {
+            const uint32_t r0 = blk * BR + 16 * rb + 4 * kg;
             if (METRIC != COSINE) aux[rb] = *reinterpret_cast<const f32x4*>(row_nrm + r0);
             if (METRIC == EUCLIDEAN) aux2[rb] = *reinterpret_cast<const f32x4*>(row_sqn + r0);
         }
@@ -660,7 +678,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
 #pragma unroll
         for (int s = 0; s < KSP; ++s)
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) afrag[rb][s] = *reinterpret_cast<const bf16x8*>(p + rb * (16 * ROW_BYTES) + s * 1024);
+            for (int rb = 0; rb < RBN; ++rb) afrag[rb][s] = *reinterpret_cast<const bf16x8*>(p + rb * (16 * ROW_BYTES) + s * 1024);
         if (!AUX_JIT) load_aux(b);
     }
 
@@ -699,46 +717,45 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
     };
 
 #ifdef RS_STAGGER  // diagnostic: the second-dispatched half of the workgroup starts late (s_sleep counts 64 cycles)
-    if (wave >= RS_NWAVES / 2) __builtin_amdgcn_s_sleep(RS_STAGGER);
+    if (wave >= NW / 2) __builtin_amdgcn_s_sleep(RS_STAGGER);
 #endif
 #ifdef RS_PRIO
-    if (wave >= RS_NWAVES / 2) __builtin_amdgcn_s_setprio(1);
+    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
 #endif
     for (; b < blk_end; b += stride) {
         const uint32_t nb_raw = b + stride;
         const uint32_t nb = nb_raw < blk_end ? nb_raw : b_last;  // the tail re-reads a valid block; its values are never used
         const unsigned char* pn = a_ptr(nb);
         const unsigned char* pc = a_ptr(b);
-        const uint32_t row0 = b * 32;
-        const bool partial = row0 + 32 > n_rows;  // wave-uniform
+        const uint32_t row0 = b * BR;
+        const bool partial = row0 + BR > n_rows;  // wave-uniform
 #if defined(RS_DBG_NOLDS) || defined(RS_DBG_NOLOAD)  // diagnostic: the fragments are opaque per block (no hoisting of the MFMAs)
 #pragma unroll
         for (int i2 = 0; i2 < NB; ++i2)
 #pragma unroll
             for (int j2 = 0; j2 < HQB; ++j2) asm volatile("" : "+v"(bq[i2][j2]));
 #pragma unroll
-        for (int s2 = 0; s2 < KSP; ++s2) {
-            asm volatile("" : "+v"(afrag[0][s2]));
-            asm volatile("" : "+v"(afrag[1][s2]));
-        }
+        for (int s2 = 0; s2 < KSP; ++s2)
+#pragma unroll
+            for (int rb2 = 0; rb2 < RBN; ++rb2) asm volatile("" : "+v"(afrag[rb2][s2]));
 #endif
-        f32x4 aux_cp[2], aux2_cp[2];               // PH = 1: this block's per-row scalars (the registers are reloaded below)
+        f32x4 aux_cp[RBN], aux2_cp[RBN];           // PH = 1: this block's per-row scalars (the registers are reloaded below)
         if (!AUX_JIT) {
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
+            for (int rb = 0; rb < RBN; ++rb) {
                 aux_cp[rb] = (METRIC != COSINE) ? aux[rb] : f32x4{1.f, 1.f, 1.f, 1.f};
                 aux2_cp[rb] = (METRIC == EUCLIDEAN) ? aux2[rb] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
         auto& aux_c = AUX_JIT ? aux : aux_cp;
         auto& aux2_c = AUX_JIT ? aux2 : aux2_cp;
-        f32x4 acc[2][HQB];
+        f32x4 acc[RBN][HQB];
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int half = (QH == 2) ? u : 0;  // which 4 query blocks this sub-iteration serves
             if (PH == 1 || u == 0) {
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
+                for (int rb = 0; rb < RBN; ++rb)
 #pragma unroll
                     for (int j = 0; j < HQB; ++j) acc[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -764,12 +781,12 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
 #pragma unroll
                 for (int j = 0; j < HQB; ++j)
 #pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
+                    for (int rb = 0; rb < RBN; ++rb)
                         acc[rb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[rb][s], bq[i % NB][j], acc[rb][j], 0, 0, 0);
 #ifndef RS_DBG_NOLOAD
                 if (reload) {  // last use of this K-step's row fragments: refill the registers
 #pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
+                    for (int rb = 0; rb < RBN; ++rb)
                         afrag[rb][s] = *reinterpret_cast<const bf16x8*>(psrc + rb * (16 * ROW_BYTES) + s * 1024);
                     if (!AUX_JIT && u == NU - 1 && s == KSP - 1) load_aux(nb);
                 }
@@ -783,13 +800,13 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
                 }
                 if (reload) {
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) {
+                    for (int g = 0; g < RBN; ++g) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
                         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * HQB - HQB - 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, RBN * HQB - HQB - RBN, 0);
                 } else {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * HQB - HQB, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, RBN * HQB - HQB, 0);
                 }
 #endif
                 __builtin_amdgcn_sched_barrier(0);
@@ -798,7 +815,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
             {
                 float keep = 0.f;
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
+                for (int rb = 0; rb < RBN; ++rb)
 #pragma unroll
                     for (int j = 0; j < HQB; ++j) keep += acc[rb][j][0] + acc[rb][j][1] + acc[rb][j][2] + acc[rb][j][3];
                 run_max[u] += keep;
@@ -809,24 +826,38 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
             // masking them costs a compare and two selects per key -- in every block, if it is written as a predicate.
             auto epilogue = [&](auto partial_tag) {
                 constexpr bool PARTIAL = decltype(partial_tag)::value;
-                float keys[HQB][8];
+                // key of row (rb, jj) for query block j, from the finished sums.  The common path only needs each query
+                // block's maximum; the rare candidate path recomputes the keys it looks at (the same arithmetic on the same
+                // registers: the accumulators stay live until the next block zeroes them), so no key array stays live across
+                // the branch -- with the 4 x 8 wave tile that array alone would be 128 registers.
+                auto key_of = [&](int rb, int j, int jj) -> float {
+                    float key = acc[rb][j][jj];                                                   // cosine: x^.q
+                    if (METRIC == DOT) key *= aux_c[rb][jj];                                      // x.q
+                    if (METRIC == EUCLIDEAN) key = 2.0f * key * aux_c[rb][jj] - aux2_c[rb][jj];   // |q|^2 - |x - q|^2
+                    if (PARTIAL && row0 + (uint32_t)(16 * rb + 4 * kg + jj) >= n_rows) key = -INFINITY;
+                    return key;
+                };
                 float mj[HQB];
 #pragma unroll
                 for (int j = 0; j < HQB; ++j) {
-#pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            float key = acc[rb][j][jj];                                                   // cosine: x^.q
-                            if (METRIC == DOT) key *= aux_c[rb][jj];                                      // x.q
-                            if (METRIC == EUCLIDEAN) key = 2.0f * key * aux_c[rb][jj] - aux2_c[rb][jj];   // |q|^2 - |x - q|^2
-                            if (PARTIAL && row0 + (uint32_t)(16 * rb + 4 * kg + jj) >= n_rows) key = -INFINITY;
-                            keys[j][4 * rb + jj] = key;
-                        }
-                    // max of the 8 keys in 3 instructions (fmaxf() costs a canonicalising v_max x, x per operand in IEEE
+                    // max of the 4 RBN keys, three at a time (fmaxf() costs a canonicalising v_max x, x per operand in IEEE
                     // mode; the keys are MFMA sums of finite bf16 products)
-                    mj[j] = max3f(max3f(keys[j][0], keys[j][1], keys[j][2]), max3f(keys[j][3], keys[j][4], keys[j][5]),
-                                  max3f(keys[j][6], keys[j][7], keys[j][7]));
+                    float m = max3f(key_of(0, j, 0), key_of(0, j, 1), key_of(0, j, 2));
+                    m = max3f(m, key_of(0, j, 3), key_of(1, j, 0));
+                    m = max3f(m, key_of(1, j, 1), key_of(1, j, 2));
+                    if (RBN == 2) {
+                        m = max3f(m, key_of(1, j, 3), key_of(1, j, 3));
+                    } else {
+                        m = max3f(m, key_of(1, j, 3), key_of(2, j, 0));
+                        m = max3f(m, key_of(2, j, 1), key_of(2, j, 2));
+                        m = max3f(m, key_of(2, j, 3), key_of(RBN - 1, j, 0));
+                        m = max3f(m, key_of(RBN - 1, j, 1), key_of(RBN - 1, j, 2));
+                        m = max3f(m, key_of(RBN - 1, j, 3), key_of(RBN - 1, j, 3));
+                    }
+                    mj[j] = m;
+                    // one query block at a time: left alone the scheduler computes every key of the sub-iteration first
+                    // (16 RBN x HQB live values -- the 4 x 8 Euclidean tile then needs more than the 512 registers there are)
+                    if (RBN == 4 && METRIC != COSINE) __builtin_amdgcn_sched_barrier(0);
                 }
                 if (MODE == 0) {
 #pragma unroll
@@ -850,12 +881,13 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
                     const float tq = thr_q[qb];
                     if (__builtin_amdgcn_ballot_w64(mj[j] >= tq) == 0ull) continue;  // wave-uniform
 #pragma unroll
-                    for (int rb = 0; rb < 2; ++rb) {
-                        const float mrb = fmaxf(fmaxf(keys[j][4 * rb], keys[j][4 * rb + 1]), fmaxf(keys[j][4 * rb + 2], keys[j][4 * rb + 3]));
+                    for (int rb = 0; rb < RBN; ++rb) {
+                        const float k0 = key_of(rb, j, 0), k1 = key_of(rb, j, 1), k2 = key_of(rb, j, 2), k3 = key_of(rb, j, 3);
+                        const float mrb = fmaxf(fmaxf(k0, k1), fmaxf(k2, k3));
                         if (__builtin_amdgcn_ballot_w64(mrb >= tq) == 0ull) continue;  // wave-uniform
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) {
-                            const float key = keys[j][4 * rb + jj];
+                            const float key = jj == 0 ? k0 : (jj == 1 ? k1 : (jj == 2 ? k2 : k3));
                             const bool is_cand = key >= tq && key > -INFINITY;  // masked rows are -inf; T_q may be too
                             const unsigned long long mk = __builtin_amdgcn_ballot_w64(is_cand);
                             if (mk != 0ull) {  // wave-uniform
@@ -900,7 +932,7 @@ __global__ __launch_bounds__(RS_NWAVES * 64) void k_mfma_rows(const __bf16* __re
             float mx = run_max[qb];  // the four k-groups of lanes saw different rows of one query
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const uint32_t gl = (uint32_t)wave * gpw / RS_NWAVES;  // this wave's group within the workgroup
+            const uint32_t gl = (uint32_t)wave * gpw / NW;  // this wave's group within the workgroup
             if (kg == 0) atomicMax(&gmax_lds[gl * QPB + qb * 16 + c16], enc_f(mx));
         }
         __syncthreads();
@@ -1383,6 +1415,34 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
             const int r_stages = fp.stages;
             const uint32_t* st_end = fp.st_end;
             bool r_launched = false;
+            // Shape of pass 1 (MODE 1): "4x64" = one wave per SIMD on 64-row blocks (round 4), "8x32" = two waves per SIMD on
+            // 32-row blocks (rounds 2-3).  The sampling pass (MODE 0, 1/32 .. 1/64 of the rows) keeps the 8-wave shape: its group
+            // bookkeeping (gpw groups per workgroup) is written for it.  VL_MFMA_ROWS_SHAPE picks; the default is the measured faster one.
+            // Shape of pass 1 (MODE 1).  Shipped: "8x32", two waves per SIMD on 32-row blocks.  A build with -DRS_WIDE_SHAPES also
+            // holds "4x64" (one wave per SIMD on 64-row blocks with the 512-register file; VL_MFMA_ROWS_SHAPE=4x64 picks it per
+            // launch sequence, tools/rows_shape_ab.py alternates the two in one process).  Measured in round 4 and NOT shipped:
+            // 8-28 % slower than 8x32 on every stride (profiles/r04_k4r_shapes_anatomy.txt) -- one wave per SIMD has nobody to
+            // hide its epilogue and its waits behind.  The sampling pass (MODE 0) keeps the 8-wave shape either way.
+#ifdef RS_WIDE_SHAPES
+            const int wide = []() {
+                const char* v = getenv("VL_MFMA_ROWS_SHAPE");
+                return (v && v[0] == '4') ? 1 : 0;
+            }();
+#endif
+            const uint32_t n_blk64 = (uint32_t)((n_rows + 63) / 64);
+            (void)n_blk64;
+#ifdef RS_WIDE_SHAPES  /* stage ends are planned in 32-row blocks: halved (floor) at both ends, the last one ends the index */
+#define VL_RLAUNCH_WIDE(K, MET)                                                                                                 \
+    if (wide == 1) {                                                                                                            \
+        const uint32_t tb = st_end[st] / 2, te = (st + 1 == r_stages) ? n_blk64 : st_end[st + 1] / 2;                            \
+        const uint32_t gx = std::max<uint32_t>(1u, std::min<uint32_t>((te - tb + 3) / 4, wg_cap));                               \
+        hipLaunchKernelGGL((k_mfma_rows<K, 1, MET, 4, 4>), dim3(gx, r_chunks), dim3(4 * 64), 0, s, slab, row_norm,               \
+                           row_sqnorm, q16, nq, tb, te, (uint32_t)n_rows, (int*)nullptr, 0u, 1u, w.thr, w.cand, w.cnt,          \
+                           (uint32_t)MFMA_CAND_CAP);                                                                            \
+    } else
+#else
+#define VL_RLAUNCH_WIDE(K, MET)
+#endif
 #define VL_RLAUNCH2(K, MET)                                                                                                     \
     {                                                                                                                           \
         hipLaunchKernelGGL((k_mfma_rows<K, 0, MET>), dim3(gx0, r_chunks), dim3(RS_NWAVES * 64), 0, s, slab, row_norm,           \
@@ -1391,11 +1451,14 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
         hipLaunchKernelGGL(k_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.gmax, r_groups, nq, q64 + (size_t)nq * dim,     \
                            w.thr);                                                                                              \
         for (int st = 0; st < r_stages; ++st) {                                                                                 \
-            const uint32_t tb = st_end[st], te = st_end[st + 1];                                                                \
-            const uint32_t gx = std::max<uint32_t>(1u, std::min<uint32_t>((te - tb + RS_NWAVES - 1) / RS_NWAVES, wg_cap));      \
-            hipLaunchKernelGGL((k_mfma_rows<K, 1, MET>), dim3(gx, r_chunks), dim3(RS_NWAVES * 64), 0, s, slab, row_norm,        \
-                               row_sqnorm, q16, nq, tb, te, (uint32_t)n_rows, (int*)nullptr, 0u, 1u, w.thr, w.cand, w.cnt,      \
-                               (uint32_t)MFMA_CAND_CAP);                                                                        \
+            VL_RLAUNCH_WIDE(K, MET)                                                                                             \
+            {                                                                                                                   \
+                const uint32_t tb = st_end[st], te = st_end[st + 1];                                                            \
+                const uint32_t gx = std::max<uint32_t>(1u, std::min<uint32_t>((te - tb + RS_NWAVES - 1) / RS_NWAVES, wg_cap));  \
+                hipLaunchKernelGGL((k_mfma_rows<K, 1, MET>), dim3(gx, r_chunks), dim3(RS_NWAVES * 64), 0, s, slab, row_norm,    \
+                                   row_sqnorm, q16, nq, tb, te, (uint32_t)n_rows, (int*)nullptr, 0u, 1u, w.thr, w.cand, w.cnt,  \
+                                   (uint32_t)MFMA_CAND_CAP);                                                                    \
+            }                                                                                                                   \
             if (st + 1 < r_stages)                                                                                              \
                 hipLaunchKernelGGL(k_refine_thresholds, dim3((nq + 3) / 4), dim3(256), 0, s, w.cand, w.cnt,                     \
                                    (uint32_t)MFMA_CAND_CAP, nq, w.thr);                                                         \

@@ -66,6 +66,7 @@ public:
     unsigned long long* d_send() const { return d_send_; }
     unsigned long long* d_recv() const { return d_recv_; }
     unsigned long long* h_send() const { return h_send_; }
+    unsigned long long* h_hdr() const { return h_hdr_; }  // pinned: the 4 header words of a record the device wrote the rest of
     int device() const { return device_; }
 
 private:
@@ -74,6 +75,7 @@ private:
     unsigned long long* d_send_ = nullptr;
     unsigned long long* d_recv_ = nullptr;
     unsigned long long* h_send_ = nullptr;  // pinned
+    unsigned long long* h_hdr_ = nullptr;   // pinned, SHARD_HDR_WORDS words
     uint64_t send_cap_ = 0, recv_cap_ = 0;
     unsigned long long* d_out_ = nullptr;   // gpos | ids | scores | n | status
     unsigned long long* h_out_ = nullptr;   // pinned
@@ -98,6 +100,9 @@ public:
     // events) the H2D copy of this rank's record, the ncclAllGather, the merge kernel + D2H of the answer
     void profile_enable(bool on);
     void profile_read(uint64_t* calls, double* local_ms, double* h2d_ms, double* allgather_ms, double* merge_ms);
+    // of the batches answered so far: how many had their exchange record written on the device by the finalize kernel (only
+    // the 32-byte header then crosses PCIe in front of the all-gather) / how many went through the pinned host record
+    void record_paths(uint64_t* on_device, uint64_t* via_host) const;
 
 private:
     ShardComm(int world, int rank, int device) : world_(world), rank_(rank), merger_(device) {}
@@ -109,6 +114,7 @@ private:
     unsigned long long* h_status_ = nullptr;    // pinned, same shape
     hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
     bool profile_ = false;
+    uint64_t rec_device_ = 0, rec_host_ = 0;
     uint64_t prof_calls_ = 0;
     double prof_local_ms_ = 0.0, prof_h2d_ms_ = 0.0, prof_allgather_ms_ = 0.0, prof_merge_ms_ = 0.0;
     int world_, rank_;

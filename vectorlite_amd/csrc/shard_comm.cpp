@@ -102,6 +102,7 @@ ShardMerger::~ShardMerger()
     if (d_send_) (void)hipFree(d_send_);
     if (d_recv_) (void)hipFree(d_recv_);
     if (h_send_) (void)hipHostFree(h_send_);
+    if (h_hdr_) (void)hipHostFree(h_hdr_);
     if (d_out_) (void)hipFree(d_out_);
     if (h_out_) (void)hipHostFree(h_out_);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -126,6 +127,7 @@ int ShardMerger::ensure(uint64_t world, uint64_t nq, uint64_t ks, uint64_t k_out
 {
     SH_HIP(hipSetDevice(device_));
     if (!stream_) SH_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    if (!h_hdr_) SH_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_hdr_), SHARD_HDR_WORDS * 8, hipHostMallocDefault));
     const uint64_t words = shard_packed_words(nq, ks);
     if (words > send_cap_) {
         if (d_send_) (void)hipFree(d_send_);
@@ -433,14 +435,43 @@ int ShardComm::search_batch(const GpuFlatIndex* shard, const double* queries, ui
     if (rc != OK) return rc;
     const bool prof = profile_;
     const auto t_local = std::chrono::steady_clock::now();
-    // from here to the all-gather nothing returns: a local failure travels in word 0 of this rank's record
-    shard_search_local(shard, offset_, lens_[(size_t)rank_], total_ != 0, queries, nq, q_len, ks, metric, merger_.h_send(),
-                       queries_on_device);
+    // from here to the all-gather nothing returns: a local failure travels in word 0 of this rank's record.
+    // First choice: the finalize kernel writes this rank's record where the all-gather reads it (d_send) -- no pinned host
+    // record, no H2D copy of it, only the 4 header words cross PCIe; batches that do not take the MFMA filter (and every
+    // failure) build the record on the host as before.
+    bool on_device = false;
+    {
+        int drc = OK;
+        try {
+            drc = shard->search_batch_to_record(queries, queries_on_device, nq, q_len, ks, metric, offset_, merger_.d_send(), &on_device);
+        } catch (...) {
+            drc = ERR_DEVICE;
+            on_device = false;
+        }
+        if (drc != OK) on_device = false;  // the host path below repeats the search and reports the failure in word 0
+        if (on_device && shard->len() != lens_[(size_t)rank_]) on_device = false;  // mutated since sync(): the host path says so
+    }
+    std::string local_msg;
+    if (on_device) {
+        unsigned long long* hdr = merger_.h_hdr();
+        hdr[0] = OK;
+        hdr[1] = lens_[(size_t)rank_];
+        hdr[2] = dim_;
+        hdr[3] = 0;
+        ++rec_device_;
+    } else {
+        shard_search_local(shard, offset_, lens_[(size_t)rank_], total_ != 0, queries, nq, q_len, ks, metric, merger_.h_send(),
+                           queries_on_device);
+        if (merger_.h_send()[0] != 0) local_msg = std::string(last_error());
+        ++rec_host_;
+    }
     const double local_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_local).count();
-    const std::string local_msg = merger_.h_send()[0] != 0 ? std::string(last_error()) : std::string();
     SH_HIP_OR_ABORT(hipSetDevice(merger_.device()));
     if (prof) SH_HIP_OR_ABORT(hipEventRecord(ev_[0], merger_.stream()));
-    SH_HIP_OR_ABORT(hipMemcpyAsync(merger_.d_send(), merger_.h_send(), words * 8, hipMemcpyHostToDevice, merger_.stream()));
+    if (on_device)
+        SH_HIP_OR_ABORT(hipMemcpyAsync(merger_.d_send(), merger_.h_hdr(), SHARD_HDR_WORDS * 8, hipMemcpyHostToDevice, merger_.stream()));
+    else
+        SH_HIP_OR_ABORT(hipMemcpyAsync(merger_.d_send(), merger_.h_send(), words * 8, hipMemcpyHostToDevice, merger_.stream()));
     if (prof) SH_HIP_OR_ABORT(hipEventRecord(ev_[1], merger_.stream()));
     // THE exchange step of the path: one all-gather of per-shard top-k records (config 3: 1024 queries x k 10
     // -> 254 KB per rank), latency-bound on xGMI -- one collective, not a ring of small ones
@@ -469,6 +500,12 @@ int ShardComm::search_batch(const GpuFlatIndex* shard, const double* queries, ui
     }
     if (rc != OK && !local_msg.empty()) set_last_error(std::string(last_error()) + "; this rank: " + local_msg);
     return rc;
+}
+
+void ShardComm::record_paths(uint64_t* on_device, uint64_t* via_host) const
+{
+    if (on_device) *on_device = rec_device_;
+    if (via_host) *via_host = rec_host_;
 }
 
 void ShardComm::profile_enable(bool on)

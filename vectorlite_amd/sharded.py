@@ -119,6 +119,12 @@ class Comm:
         self._L.vl_comm_profile_read(self._h, C.byref(calls), C.byref(a), C.byref(b), C.byref(c), C.byref(d))
         return {"calls": int(calls.value), "local_ms": a.value, "h2d_ms": b.value, "allgather_ms": c.value, "merge_ms": d.value}
 
+    def record_paths(self) -> dict:
+        """Batches whose exchange record the finalize kernel wrote on the device / that built it on the host."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._L.vl_comm_record_paths(self._h, C.byref(a), C.byref(b))
+        return {"on_device": int(a.value), "via_host": int(b.value)}
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.vl_comm_destroy(self._h)
