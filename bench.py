@@ -91,6 +91,7 @@ def parse_args(argv=None):
     p.add_argument("--c3-shards", type=int, default=8)
     p.add_argument("--c3-dim", type=int, default=768)
     p.add_argument("--c3-batch", type=int, default=1024)
+    p.add_argument("--no-c4-sweep", action="store_true", help="skip config 4's ef_construction sweep (two more builds per embedding-like distribution)")
     p.add_argument("--no-c3-full", action="store_true", help="skip config 3 at its own size on one card (8 shards of the 10 M x 768 corpus)")
     p.add_argument("--c4-rows", type=int, default=1_000_000)
     p.add_argument("--c4-queries", type=int, default=1000)
@@ -576,44 +577,73 @@ def run_c3_full_one_card(V, torch, args, dev, dev_index, k, shards, starts):
     return out
 
 
+def gen_c4_rows(torch, dev, kind, n, dim, seed, state):
+    """Config 4's row distributions.  latent16: A z + 0.05 noise, z in R^16 (low intrinsic dimension); clustered: 2000 topical
+    clusters on the sphere (centre + 0.35 / sqrt(dim) gaussian per coordinate) -- the other shape sentence embeddings take;
+    iid_gaussian: SURVEY 8(d)'s i.i.d. N(0, 1) unit rows (near-equidistant: no graph index answers them)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    if kind == "latent16":
+        x = torch.randn((n, 16), dtype=torch.float64, device=dev, generator=g) @ state["A"]
+        x += 0.05 * torch.randn((n, dim), dtype=torch.float64, device=dev, generator=g)
+    elif kind == "clustered":
+        which = torch.randint(0, state["C"].shape[0], (n,), device=dev, generator=g)
+        x = state["C"][which] + (0.35 / dim ** 0.5) * torch.randn((n, dim), dtype=torch.float64, device=dev, generator=g)
+    else:
+        x = torch.randn((n, dim), dtype=torch.float64, device=dev, generator=g)
+    x /= torch.linalg.vector_norm(x, dim=1, keepdim=True)
+    return x
+
+
 def run_c4(V, torch, args, dev, dev_index, k, cap_s, log_fn):
-    """BASELINE config 4 (HNSW, default profile M 16 / M0 32, cosine, dim of the run): build on the GPU, recall@10 against
-    the exhaustive order, batched QPS and distance evaluations per query at ef 10 (the reference's ef = min(k, len),
-    src/index/hnsw.rs:437), 32 and 128 -- on embedding-like rows (latent dimension 16) AND on SURVEY 8(d)'s i.i.d.
-    gaussian unit rows.  The walk is this repository's own (crate hnsw 0.11.0 is not in the reference tree): parity
-    with the crate's walk is UNPINNED, the numbers are recall, not parity."""
+    """BASELINE config 4 (HNSW, default profile M 16 / M0 32, cosine, dim of the run): build on the GPU with the library's
+    default ef_construction (400 = what the crate's Params::default() is recalled to be, SURVEY 9.5), recall@10 against the
+    exhaustive order, batched QPS and distance evaluations per query at ef 10 (the reference's ef = min(k, len),
+    src/index/hnsw.rs:437), 32 and 128, a lone query's latency at the strict beam with the CPU walk of the same graph at the
+    SAME beam beside it, the CPU walk at ef 128 ("recall@10 vs CPU HNSW"), and the ef_construction sweep
+    {128, 200, 400} at the strict beam -- on two embedding-like distributions and on SURVEY 8(d)'s i.i.d. rows.  The walk is
+    this repository's own (crate hnsw 0.11.0 is not in the reference tree): parity with the crate's walk is UNPINNED, the
+    numbers are recall, not parity."""
     t_block = time.perf_counter()
     n, dim, nq = args.c4_rows, args.dim, args.c4_queries
-    res = {"workload": f"HNSW cosine, N={n}, dim={dim}, M=16 M0=32 ef_construction=128, {nq}-query batches, k={k}",
+    efc_default = 400
+    res = {"workload": f"HNSW cosine, N={n}, dim={dim}, M=16 M0=32 ef_construction={efc_default} (library default), {nq}-query batches, k={k}",
            "parity": "unpinned (own walk; the crate's is not in the reference tree)", "data": {}}
-    for name, latent in (("latent16", 16), ("iid_gaussian", 0)):
-        if time.perf_counter() - t_block > cap_s:
-            res["data"][name] = {"skipped": "block time cap"}
-            continue
-        g = torch.Generator(device=dev)
-        g.manual_seed(99 + latent)
-        A = torch.randn((latent, dim), dtype=torch.float64, device=dev, generator=g) if latent else None
-        flat = V.FlatIndex(dim, device=dev_index)
-        flat.reserve(n)
-        hn = V.HNSWIndex(dim, 0, device=dev_index)
-        t_build = 0.0
-        done = 0
+
+    def build(kind, state, efc, with_flat):
+        flat = None
+        if with_flat:
+            flat = V.FlatIndex(dim, device=dev_index)
+            flat.reserve(n)
+        hn = V.HNSWIndex(dim, 0, device=dev_index, ef_construction=efc)
+        t_build, done = 0.0, 0
         while done < n:
             c = min(250_000, n - done)
-            x = gen_unit_rows(torch, dev, c, dim, 31337 + done + latent, A)
+            x = gen_c4_rows(torch, dev, kind, c, dim, 31337 + done, state)
             ids = np.arange(done, done + c, dtype=np.uint64)
-            flat.add_rows(ids, x, validate=False)
+            if flat is not None:
+                flat.add_rows(ids, x, validate=False)
             tb = time.perf_counter()
             hn.add_rows(ids, x)
             t_build += time.perf_counter() - tb
             done += c
             del x
-        rng = np.random.default_rng(4321 + latent)
-        if A is None:
-            Q = rng.standard_normal((nq, dim))
-        else:
-            Q = rng.standard_normal((nq, latent)) @ A.cpu().numpy() + 0.05 * rng.standard_normal((nq, dim))
-        Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+        return flat, hn, t_build
+
+    for name in ("latent16", "clustered", "iid_gaussian"):
+        if time.perf_counter() - t_block > cap_s:
+            res["data"][name] = {"skipped": "block time cap"}
+            continue
+        g = torch.Generator(device=dev)
+        g.manual_seed(99 + len(name))
+        state = {}
+        if name == "latent16":
+            state["A"] = torch.randn((16, dim), dtype=torch.float64, device=dev, generator=g)
+        elif name == "clustered":
+            cc = torch.randn((2000, dim), dtype=torch.float64, device=dev, generator=g)
+            state["C"] = cc / torch.linalg.vector_norm(cc, dim=1, keepdim=True)
+        flat, hn, t_build = build(name, state, efc_default, True)
+        Q = gen_c4_rows(torch, dev, name, nq, dim, 4321, state).cpu().numpy()
         ti, _, _ = flat.search_batch(Q, k, 0)  # exhaustive f64 order
         # the graph only sees the reference's quantised u64 distances (src/index/hnsw.rs:113-174): recall is also
         # counted against THAT order (ties at the k-th distance accepted), on a subset
@@ -621,10 +651,10 @@ def run_c4(V, torch, args, dev, dev_index, k, cap_s, log_fn):
         allpos = np.arange(n, dtype=np.uint64)
         D = [flat.hnsw_distances(Q[i], allpos, 0) for i in range(nchk)]
         kth = [np.partition(d, k - 1)[k - 1] for d in D]
+        rec_of = lambda hi_, hnn, m: float(np.mean([len(set(hi_[i, :int(hnn[i])].tolist()) & set(ti[i].tolist())) / float(k) for i in range(m)]))  # noqa: E731
         per_ef = {}
         for ef in (10, 32, 128):
             strict = ef == 10
-            hn.set_min_beam(0 if strict else 32)
             hn.search_batch(Q[:8], k, 0, ef=(0 if strict else ef))
             q0, e0 = hn.walk_stats()
             tq = time.perf_counter()
@@ -632,7 +662,7 @@ def run_c4(V, torch, args, dev, dev_index, k, cap_s, log_fn):
             dtq = time.perf_counter() - tq
             q1, e1 = hn.walk_stats()
             evq = (e1 - e0) / max(q1 - q0, 1)
-            rec = float(np.mean([len(set(hi_[i, :int(hnn[i])].tolist()) & set(ti[i].tolist())) / float(k) for i in range(nq)]))
+            rec = rec_of(hi_, hnn, nq)
             recq = float(np.mean([sum(1 for x in hi_[i, :int(hnn[i])] if D[i][int(x)] <= kth[i]) / float(k) for i in range(nchk)]))
             row_bytes = (evq - max(ef, k)) * dim * 4 + max(ef, k) * dim * 8
             gbps = (nq / dtq) * row_bytes / 1e9
@@ -643,7 +673,6 @@ def run_c4(V, torch, args, dev, dev_index, k, cap_s, log_fn):
                                              "note": "random 1.5-3 KB row reads of a latency-bound walk: rows read x row bytes / time"},
                                 "beam": "strict reference rule ef = min(k, len)" if strict else f"ef = {ef}"}
         # a lone query at the reference's strict beam
-        hn.set_min_beam(0)
         lat = []
         for i in range(20):
             tl = time.perf_counter()
@@ -651,9 +680,10 @@ def run_c4(V, torch, args, dev, dev_index, k, cap_s, log_fn):
             lat.append(time.perf_counter() - tl)
         # BASELINE config 4's own words: "recall@10 vs CPU HNSW".  The graph is exported (vl_index_hnsw_graph_export) and
         # oracle/vl_hnsw_cpu.c -- the checker's single-threaded walk with the reference's f64 -> u64 callbacks
-        # (src/index/hnsw.rs:113-174) -- walks the SAME graph at ef 128 on a few queries: its recall, its time per
-        # query, and the GPU walk's recall on the same queries.  (A CPU baseline leg: the oracle is the checker here.)
-        cpu_walk = None
+        # (src/index/hnsw.rs:113-174) -- walks the SAME graph: at ef 128 (recall against the GPU walk's) and at the reference's
+        # strict beam ef 10 (its time per query beside the GPU's lone-query latency above: SURVEY H5, like for like).
+        # (A CPU baseline leg: the oracle is the checker here.)
+        cpu_walk, cpu_walk10 = None, None
         try:
             from oracle import oracle as O
             n_cpu = min(nchk, 12)
@@ -662,22 +692,51 @@ def run_c4(V, torch, args, dev, dev_index, k, cap_s, log_fn):
             tw = time.perf_counter()
             cw = [walker.search(Q[i], 128, k) for i in range(n_cpu)]
             t_cpu = (time.perf_counter() - tw) / n_cpu
+            ev128 = walker.evals.value
             gi, _, gn = hn.search_batch(Q[:n_cpu], k, 0, ef=128)
             in_top = lambda i, ids_: sum(1 for x in ids_ if D[i][int(x)] <= kth[i]) / float(k)  # noqa: E731
             cpu_walk = {"queries": n_cpu, "ef": 128, "cores": 1,
                         "cpu_recall_at_10_vs_u64_distance_order": round(float(np.mean([in_top(i, cw[i][0]) for i in range(n_cpu)])), 4),
                         "gpu_recall_at_10_same_queries": round(float(np.mean([in_top(i, gi[i, :int(gn[i])]) for i in range(n_cpu)])), 4),
                         "cpu_ms_per_query": round(t_cpu * 1e3, 3),
-                        "cpu_distance_evals_per_query": round(walker.evals.value / n_cpu, 1),
+                        "cpu_distance_evals_per_query": round(ev128 / n_cpu, 1),
                         "walker": "oracle/vl_hnsw_cpu.c on the graph this index built (parity with crate hnsw 0.11.0's walk: unpinned)"}
+            n10 = min(nchk, 24)
+            walker.evals.value = 0
+            tw = time.perf_counter()
+            cw10 = [walker.search(Q[i], 10, k) for i in range(n10)]
+            t_cpu10 = (time.perf_counter() - tw) / n10
+            g10, _, gn10 = hn.search_batch(Q[:n10], k, 0)
+            cpu_walk10 = {"queries": n10, "ef": 10, "cores": 1, "cpu_ms_per_query": round(t_cpu10 * 1e3, 4),
+                          "gpu_lone_query_ms_same_beam": round(float(np.median(lat)) * 1e3, 4),
+                          "cpu_recall_at_10_vs_u64_distance_order": round(float(np.mean([in_top(i, cw10[i][0]) for i in range(n10)])), 4),
+                          "gpu_recall_at_10_same_queries": round(float(np.mean([in_top(i, g10[i, :int(gn10[i])]) for i in range(n10)])), 4),
+                          "cpu_distance_evals_per_query": round(walker.evals.value / n10, 1)}
             del walker, graph
         except Exception as e:  # noqa: BLE001 -- the recall / QPS figures above stand without it
             cpu_walk = {"skipped": f"{type(e).__name__}: {e}"[:200]}
-        res["data"][name] = {"build_s": round(t_build, 2), "inserts_per_s": round(n / t_build, 0),
-                             "single_query_ms_strict_beam": round(float(np.median(lat)) * 1e3, 3), **per_ef,
-                             "cpu_hnsw_walk_same_graph": cpu_walk}
+        entry = {"ef_construction": efc_default, "build_s": round(t_build, 2), "inserts_per_s": round(n / t_build, 0),
+                 "single_query_ms_strict_beam": round(float(np.median(lat)) * 1e3, 3), **per_ef,
+                 "cpu_hnsw_walk_same_graph": cpu_walk, "cpu_hnsw_walk_same_graph_strict_beam": cpu_walk10}
         log_fn(f"[bench] config 4 / {name}: build {t_build:.1f}s, " + ", ".join(f"{e}: {v['recall_at_10_vs_exact_f64_order']:.3f} @ {v['queries_per_s']:.0f} q/s" for e, v in per_ef.items()))
-        del flat, hn, A
+        del hn
+        # the construction beam's share: the same rows built at 128 (rounds 1-3's value) and 200, strict beam and ef 128
+        if name != "iid_gaussian" and not args.no_c4_sweep:
+            sweep = {str(efc_default): {"build_s": entry["build_s"], "recall_at_10_strict_beam": per_ef["ef10"]["recall_at_10_vs_exact_f64_order"],
+                                        "recall_at_10_ef128": per_ef["ef128"]["recall_at_10_vs_exact_f64_order"]}}
+            for efc in (128, 200):
+                if time.perf_counter() - t_block > cap_s:
+                    sweep[str(efc)] = {"skipped": "block time cap"}
+                    continue
+                _, h2, tb2 = build(name, state, efc, False)
+                a_i, _, a_n = h2.search_batch(Q, k, 0)
+                b_i, _, b_n = h2.search_batch(Q, k, 0, ef=128)
+                sweep[str(efc)] = {"build_s": round(tb2, 2), "recall_at_10_strict_beam": round(rec_of(a_i, a_n, nq), 4),
+                                   "recall_at_10_ef128": round(rec_of(b_i, b_n, nq), 4)}
+                del h2
+            entry["ef_construction_sweep"] = sweep
+        res["data"][name] = entry
+        del flat, state
         torch.cuda.empty_cache()
     return res
 
@@ -1208,7 +1267,7 @@ def run_rank(args) -> int:
             "note": "concurrent callers share slab passes (bf16 MFMA filter + exact f64 finalize): every answer is the lone search's"}
 
     def c4_block():
-        other["c4_hnsw"] = run_c4(V, torch, args, dev, dev_index, k, args.block_cap_s, log)
+        other["c4_hnsw"] = run_c4(V, torch, args, dev, dev_index, k, args.block_cap_s * 2.5, log)  # three builds at ef_construction 400 + the sweep
 
     # ---- one reference-faithful CPU query at FULL size (SURVEY 8(d) "run d384 fully"): is the x N scaling above true? ----
     def cpu_full_block():

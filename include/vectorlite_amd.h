@@ -110,7 +110,10 @@ int vl_index_parts(const vl_index *h, int *n_parts, int *mode, uint64_t *rows, u
  * u64 distances to scores (:51-75, :478-479), stable-sorts and truncates (:493-494).
  * The graph walk itself is this library's own (crate hnsw 0.11.0 is not part of the reference tree): it
  * navigates by f32 distances and gives every node of the final beam the reference's exact f64 callback value,
- * from which the returned scores are computed; results are approximate and judged by recall. */
+ * from which the returned scores are computed; results are approximate and judged by recall.
+ * vl_hnsw_create builds with ef_construction = 400 -- what crate hnsw 0.11.0's Params::default() is recalled to be (the
+ * reference passes no parameters, src/index/hnsw.rs:226-244; the crate is not in the reference tree, so unverified);
+ * vl_hnsw_create_ex takes M, M0 (<= 64), ef_construction (1..512) and the level seed. */
 int vl_hnsw_create(uint64_t dim, int metric, int device, vl_index **out);
 int vl_hnsw_create_ex(uint64_t dim, int metric, uint32_t m, uint32_t m0, uint32_t ef_construction, uint64_t seed,
                       int device, vl_index **out);

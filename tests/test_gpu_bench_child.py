@@ -82,8 +82,13 @@ def test_bench_child_process_prints_the_whole_contract_line(steps, warmup):
     assert cc["threads"] == 16 and cc["identical_to_lone_search"] == "16/16" and cc["value"] > 0
     assert cc["passes"] <= cc["queries"] and cc["latency_ms"]["p99"] >= cc["latency_ms"]["p50"] > 0
     c4 = oc["c4_hnsw"]
-    assert c4["parity"].startswith("unpinned") and set(c4["data"]) == {"latent16", "iid_gaussian"}
-    for dist_name in ("latent16", "iid_gaussian"):
+    assert c4["parity"].startswith("unpinned") and set(c4["data"]) == {"latent16", "clustered", "iid_gaussian"}
+    for dist_name in ("latent16", "clustered"):   # the construction beam's sweep: 128 (rounds 1-3), 200, 400 (the default)
+        sw = c4["data"][dist_name]["ef_construction_sweep"]
+        assert set(sw) == {"128", "200", "400"} and all(0.0 <= v["recall_at_10_strict_beam"] <= v["recall_at_10_ef128"] + 0.05 for v in sw.values())
+        c10 = c4["data"][dist_name]["cpu_hnsw_walk_same_graph_strict_beam"]   # SURVEY H5, like for like: the reference's beam on both sides
+        assert c10["ef"] == 10 and c10["cpu_ms_per_query"] > 0 and c10["gpu_lone_query_ms_same_beam"] > 0
+    for dist_name in ("latent16", "clustered", "iid_gaussian"):
         d = c4["data"][dist_name]
         for ef in ("ef10", "ef32", "ef128"):
             assert 0.0 <= d[ef]["recall_at_10_vs_exact_f64_order"] <= 1.0 and d[ef]["roofline"]["frac"] >= 0

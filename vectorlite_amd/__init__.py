@@ -536,7 +536,7 @@ class HNSWIndex:
     (crate hnsw 0.11.0 is not in the reference tree), so results are approximate: judged by recall."""
 
     def __init__(self, dim: int, metric: int = SimilarityMetric.Cosine, device: int = 0, m: int = 16, m0: int = 32,
-                 ef_construction: int = 128, seed: int = 0, _handle=None):
+                 ef_construction: int = 400, seed: int = 0, _handle=None):
         self._L = _lib.load()
         self._meta: Dict[int, Tuple[str, Any]] = {}
         self._h = C.c_void_p()

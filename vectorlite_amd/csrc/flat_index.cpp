@@ -91,7 +91,7 @@ Workspace::~Workspace()
     void* host[] = {h_q64, h_result, h_nan, mf_h_q64, mf_h_result, mf_h_dom};
     for (void* p : host)
         if (p) (void)hipHostFree(p);
-    void* mfd[] = {mf.q_bf16, mf.gmax, mf.thr, mf.cand, mf.cnt, mf_d_q64, mf_lists};
+    void* mfd[] = {mf.q_bf16, mf.gmax, mf.thr, mf.cand, mf.cnt, mf_d_q64, mf_lists, mf_scores};
     for (void* p : mfd)
         if (p) (void)hipFree(p);
     if (ev0) (void)hipEventDestroy(ev0);
@@ -1356,6 +1356,7 @@ int GpuFlatIndex::ensure_mfma_scratch(Workspace* ws) const
     VL_TRY(dev_alloc(&ws->mf_d_q64, nqc * (dim_ + 1)));
     VL_TRY(pinned_alloc(&ws->mf_h_q64, nqc * (dim_ + 1)));
     VL_TRY(dev_alloc(&ws->mf_lists, nqc * KP));
+    VL_TRY(dev_alloc(&ws->mf_scores, nqc * KP));
     VL_TRY(pinned_alloc(&ws->mf_h_result, nqc));
     VL_TRY(pinned_alloc(&ws->mf_h_dom, nqc));
     ws->mf.nq_cap = (uint32_t)nqc;
@@ -1417,9 +1418,17 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, const 
             seq_sink = *sink;
             seq_sink.q0 = (uint32_t)q0;
         }
-        VL_HIP(launch_merge_finalize(st, metric, ws->mf_lists, 1, (int)g, d_master_, ws->mf_d_q64,
-                                     ws->mf_d_q64 + (size_t)g * dim_, (uint32_t)dim_, n, (uint32_t)k_eff, max_row_norm_,
-                                     ws->mf_h_result, in_extra, 0, sink ? &seq_sink : nullptr));
+        // batches: the rescoring split over four workgroups per query + a rank / emit launch (launch_batch_finalize); a handful
+        // of queries keeps the one-workgroup-per-query kernel (one launch less)
+        static const bool split_off = []() { const char* v = getenv("VL_BATCH_FINALIZE"); return v && v[0] == '0'; }();
+        if (g >= 8 && !split_off)
+            VL_HIP(launch_batch_finalize(st, metric, ws->mf_lists, (int)g, d_master_, ws->mf_d_q64, ws->mf_d_q64 + (size_t)g * dim_,
+                                         (uint32_t)dim_, n, (uint32_t)k_eff, max_row_norm_, ws->mf_h_result, in_extra, ws->mf_scores,
+                                         sink ? &seq_sink : nullptr));
+        else
+            VL_HIP(launch_merge_finalize(st, metric, ws->mf_lists, 1, (int)g, d_master_, ws->mf_d_q64,
+                                         ws->mf_d_q64 + (size_t)g * dim_, (uint32_t)dim_, n, (uint32_t)k_eff, max_row_norm_,
+                                         ws->mf_h_result, in_extra, 0, sink ? &seq_sink : nullptr));
         const auto t_2 = now();
         VL_HIP(hipStreamSynchronize(st));
         if (d_queries)

@@ -85,6 +85,7 @@ struct Workspace {
     double* mf_d_q64 = nullptr;             // [MFMA_MAX_BATCH, dim] queries, then their norms
     double* mf_h_q64 = nullptr;             // pinned
     Cand32* mf_lists = nullptr;             // [MFMA_MAX_BATCH, KP]
+    double* mf_scores = nullptr;            // [MFMA_MAX_BATCH, KP] reference scores of the candidates (batch finalize scratch)
     SearchResultBlock* mf_h_result = nullptr;  // pinned [MFMA_MAX_BATCH]
     unsigned char* mf_h_dom = nullptr;      // pinned [MFMA_MAX_BATCH]: in-domain flags of device-resident queries
 

@@ -24,7 +24,11 @@ double hnsw_score(uint64_t d_u64, int metric);
 struct HnswParams {
     uint32_t m = 16;                // MAXIMUM_NUMBER_CONNECTIONS   (src/index/hnsw.rs:95-101, default profile)
     uint32_t m0 = 32;               // MAXIMUM_NUMBER_CONNECTIONS_0 (src/index/hnsw.rs:103-109)
-    uint32_t ef_construction = 128; // own traversal (the crate's value is not visible from the reference)
+    uint32_t ef_construction = 400; // HNSWIndex::new calls Hnsw::new(metric) = the crate's Params::default() (src/index/hnsw.rs:226-244);
+                                    // SURVEY 9.5 recalls that default as 400 (crate hnsw 0.11.0 is not in the tree: unverified).
+                                    // Rounds 1-3 built with 128 because the beam stopped there; measured at N = 1 M x 384
+                                    // (profiles/r04_hnsw_efc_sweep_1m_d384.jsonl): 128 -> 400 lifts the strict-beam recall@10 on
+                                    // clustered rows 0.48 -> 0.57 (0.66 -> 0.76 at ef 128), nothing on latent-16 rows, build 3.6 -> 9.1 s
     uint64_t seed = 0;
 };
 

@@ -425,26 +425,30 @@ __device__ unsigned long long vl_dbg_stamps[32];
 constexpr int RP_CH = 48;               // columns per LDS tile (row stride 49 doubles: conflict-free ds_read_b64)
 constexpr int RP_NCH = 8;               // tiles per block of columns fetched from HBM together
 constexpr int RP_BW = RP_CH * RP_NCH;   // 384 columns: one memory round trip for a dim-384 row
-constexpr int RP_PER = KP * RP_CH / 1024;
-static_assert(KP * RP_CH % 1024 == 0, "tile elements divide evenly over the workgroup");
 
-template <int METRIC>
+template <int METRIC, int ROWS = KP>
 struct RescoreLds {
-    double tA[KP][RP_CH + 1];                                 // the summands of `a`
-    double tB[METRIC == COSINE ? KP : 1][RP_CH + 1];          // cosine: x * x
-    double qblk[RP_BW];                                       // the query's columns of the current block
-    double qq[METRIC == COSINE ? RP_BW : 1];                  // cosine: y * y
-    double b[KP];
+    double tA[ROWS][RP_CH + 1];                                 // the summands of `a`
+    double tB[METRIC == COSINE ? ROWS : 1][RP_CH + 1];          // cosine: x * x
+    double qblk[RP_BW];                                         // the query's columns of the current block
+    double qq[METRIC == COSINE ? RP_BW : 1];                    // cosine: y * y
+    double b[ROWS];
     double c;
 };
 
-template <int METRIC>
+// ROWS candidate rows rescored by a workgroup of NTHREADS threads (ROWS * RP_CH tile elements, RP_PER per thread):
+// 64 rows x 1024 threads for a single search's finalize, 16 rows x 256 threads for a quarter of a batch query's list.
+template <int METRIC, int ROWS, int NTHREADS>
 __device__ __forceinline__ void rescore_rows_par(const double* __restrict__ master, const double* __restrict__ q64,
                                                  uint32_t dim, const uint32_t* sh_pos, int n_rows,
-                                                 RescoreLds<METRIC>& S, Acc64<METRIC>& A, double q_first)
+                                                 RescoreLds<METRIC, ROWS>& S, Acc64<METRIC>& A,
+                                                 const double (&q_first)[(RP_BW + NTHREADS - 1) / NTHREADS])
 {
-    // q_first: q64[min(tid, dim - 1)] for tid < RP_BW, fetched by the caller at kernel entry (a single search reads
+    // q_first[j]: q64[min(tid + j NTHREADS, dim - 1)], fetched by the caller at kernel entry (a single search reads
     // its query from pinned host memory: that PCIe round trip then hides behind the list merge)
+    constexpr int RP_PER = ROWS * RP_CH / NTHREADS;
+    constexpr int QN = (RP_BW + NTHREADS - 1) / NTHREADS;
+    static_assert(ROWS * RP_CH % NTHREADS == 0 && ROWS <= WAVE, "tile elements divide evenly; one lane per row");
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1), wave = tid >> 6;
     A.init();
@@ -460,7 +464,7 @@ __device__ __forceinline__ void rescore_rows_par(const double* __restrict__ mast
             for (int i = 0; i < RP_PER; ++i) {
                 // clamped, never predicated (a load under a condition is waited for before the next one issues):
                 // rows >= n_rows are not walked and columns >= dim not summed, so the duplicates are unused
-                const int idx = tid + i * 1024;
+                const int idx = tid + i * NTHREADS;
                 int r = idx / RP_CH;
                 r = r < n_rows ? r : n_rows - 1;
                 uint32_t col = c0 + (uint32_t)(idx % RP_CH);
@@ -468,17 +472,23 @@ __device__ __forceinline__ void rescore_rows_par(const double* __restrict__ mast
                 pre[p][i] = master[(size_t)sh_pos[r] * dim + col];
             }
         }
-        double qv = q_first;
-        if (g0 != 0 && tid < RP_BW) {
-            const uint32_t col = g0 + (uint32_t)tid;
-            qv = q64[col < dim ? col : dim - 1];
+        double qv[QN];
+#pragma unroll
+        for (int j = 0; j < QN; ++j) {
+            qv[j] = q_first[j];
+            if (g0 != 0 && tid + j * NTHREADS < RP_BW) {
+                const uint32_t col = g0 + (uint32_t)(tid + j * NTHREADS);
+                qv[j] = q64[col < dim ? col : dim - 1];
+            }
         }
         VL_STAMP(4);
         __syncthreads();  // the previous block's qblk / tiles are consumed
-        if (tid < RP_BW) {
-            S.qblk[tid] = qv;
-            if (METRIC == COSINE) S.qq[tid] = qv * qv;
-        }
+#pragma unroll
+        for (int j = 0; j < QN; ++j)
+            if (tid + j * NTHREADS < RP_BW) {
+                S.qblk[tid + j * NTHREADS] = qv[j];
+                if (METRIC == COSINE) S.qq[tid + j * NTHREADS] = qv[j] * qv[j];
+            }
         __syncthreads();
         VL_STAMP(5);
 #pragma unroll
@@ -489,7 +499,7 @@ __device__ __forceinline__ void rescore_rows_par(const double* __restrict__ mast
             if (p) __syncthreads();  // the previous tile is consumed
 #pragma unroll
             for (int i = 0; i < RP_PER; ++i) {
-                const int idx = tid + i * 1024;
+                const int idx = tid + i * NTHREADS;
                 const int r = idx / RP_CH, cc = idx % RP_CH;
                 const double x = pre[p][i], y = S.qblk[p * RP_CH + cc];
                 if (METRIC == COSINE) {
@@ -528,12 +538,12 @@ __device__ __forceinline__ void rescore_rows_par(const double* __restrict__ mast
     VL_STAMP(7);
     __syncthreads();
     if (METRIC == COSINE) {
-        if (wave == 1) S.b[lane] = acc;
+        if (wave == 1 && lane < ROWS) S.b[lane] = acc;
         if (wave == 2 && lane == 0) S.c = acc;
         __syncthreads();
         if (wave == 0) {
             A.a = acc;
-            A.b = S.b[lane];
+            A.b = S.b[lane < ROWS ? lane : 0];
             A.c = S.c;
         }
     } else if (wave == 0) {
@@ -578,6 +588,129 @@ __device__ __forceinline__ double bound_for_key(float t_key, uint32_t n, double 
     return (1.0 / (1.0 + d_lo * (1.0 - 1e-12))) * (1.0 + 1e-15);
 }
 
+// Phase 3 of a finalize, one WAVE per query: lane j holds candidate j's reference score and position (lanes >= n_cand hold
+// nothing); key64 = the candidate list's 64th scan key.  Rank by (score desc, pos asc) = the reference's stable sort, run the
+// exactness bound check, write the result block (and, for a row shard, its slice of the exchange record).
+template <int METRIC>
+__device__ __forceinline__ void rank_check_emit(double sc, uint32_t my_pos, float key64, int n_cand, uint32_t k, uint64_t n_rows,
+                                                uint32_t ld, double R, double Q, double in_extra,
+                                                SearchResultBlock* __restrict__ out, uint32_t seq, const ShardRecordSink& sink,
+                                                uint32_t q_in_launch)
+{
+    const int lane = lane_id();
+    const bool valid = lane < n_cand;
+    const bool any_nan = __ballot(valid && sc != sc) != 0ull;
+    // rank = how many candidates stand in front of this one: every candidate sits in a lane of this wave, so
+    // entry j is read with v_readlane (a scalar operand of the compares), no LDS round trip per entry
+    int rank = 0;
+    for (int j = 0; j < n_cand; ++j) {
+        const double sj = read_lane(sc, j);
+        const uint32_t pj = read_lane(my_pos, j);
+        rank += (sj > sc || (sj == sc && pj < my_pos)) ? 1 : 0;
+    }
+    const uint32_t k_eff = (uint64_t)k < n_rows ? k : (uint32_t)n_rows;
+    uint32_t flags = 0;
+    if (any_nan) flags |= RESULT_HAS_NAN | RESULT_NEEDS_EXACT;
+    if (n_rows <= (uint64_t)KP) {
+        // the list must hold EVERY row; a shorter one (a candidate stage that overflowed or dropped rows)
+        // proves nothing
+        if ((uint64_t)n_cand < n_rows) flags |= RESULT_NEEDS_EXACT;
+    } else {
+        // rows outside the candidate list exist: all of them have scan key <= the 64th key
+        if (n_cand < KP) {
+            flags |= RESULT_NEEDS_EXACT;  // keys were not finite: outside the fast-path domain
+        } else {
+            const double B = bound_for_key<METRIC>(key64, ld, R, Q, in_extra);
+            // score of the entry ranked k_eff-1
+            const unsigned long long at_cut = __ballot(valid && rank == (int)k_eff - 1);
+            double s_cut = 0.0;
+            if (at_cut) s_cut = __shfl(sc, __ffsll((long long)at_cut) - 1);
+            if (!at_cut || !(s_cut > B)) flags |= RESULT_NEEDS_EXACT;
+        }
+    }
+    if (valid && rank < (int)k_eff) {
+        out->pos[rank] = my_pos;
+        out->score[rank] = sc;
+    }
+    if (lane == 0) {
+        out->n_out = k_eff;
+        out->flags = flags;
+    }
+    if (sink.cnt) {  // a row shard's exchange record, written where the all-gather reads it (shard.hpp)
+        const uint32_t q = sink.q0 + q_in_launch;
+        const uint32_t offered = (flags == 0u) ? (k_eff < sink.ks ? k_eff : sink.ks) : 0u;  // not certified: the host redoes it
+        if (valid && (uint32_t)rank < offered) {
+            const size_t e = (size_t)q * sink.ks + (uint32_t)rank;
+            sink.score_bits[e] = (unsigned long long)__double_as_longlong(sc);
+            sink.gpos[e] = sink.row_offset + (unsigned long long)my_pos;
+            sink.ids[e] = sink.pos_to_id[my_pos];
+        }
+        if (lane == 0) sink.cnt[q] = offered;
+    }
+    VL_STAMP(9);
+    if (seq) {
+        // the host spins on out->seq (pinned memory): every lane's stores of the block above are complete at
+        // system scope before the stamp leaves (this wave is the only writer of the block)
+        __threadfence_system();
+        if (lane == 0) __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    VL_STAMP(10);
+}
+
+// A BATCH's finalize (n_lists = 1: the MFMA filter's one sorted top-64 list per query) as two launches.  k_merge_finalize
+// spends a 1024-thread workgroup per query -- right for ONE search, where latency is everything -- but in a batch every
+// workgroup then issues its 196 KB of row loads at once, waits for the memory system to serve all of them, and computes with
+// one wave while 15 wait (1024 queries x 64 rows x 768 dimensions: 124 us = 3.2 TB/s of master rows).  Here a query's 64
+// candidates are rescored by FOUR workgroups of 256 threads (16 rows each: 8 workgroups per CU, out of step with each other,
+// so some load while others add), and a second launch of one wave per query ranks, checks the bound and emits.  Same
+// arithmetic, same order: per row, products by all threads, one lane adds them in index order.
+constexpr int BF_ROWS = 16;
+template <int METRIC>
+__global__ __launch_bounds__(256) void k_batch_rescore(const Cand32* __restrict__ lists, const double* __restrict__ master,
+                                                       const double* __restrict__ q64, uint32_t dim, double* __restrict__ scores)
+{
+    const uint32_t q = blockIdx.x >> 2, quarter = blockIdx.x & 3u;
+    __shared__ RescoreLds<METRIC, BF_ROWS> rs;
+    __shared__ uint32_t sh_pos[BF_ROWS];
+    __shared__ int sh_n;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    const Cand32* mine = lists + (size_t)q * KP + quarter * BF_ROWS;
+    q64 += (size_t)q * dim;
+    constexpr int QN = (RP_BW + 255) / 256;
+    double q_first[QN];
+#pragma unroll
+    for (int j = 0; j < QN; ++j) {
+        const uint32_t c = (uint32_t)(tid + j * 256);
+        q_first[j] = q64[c < dim ? c : dim - 1];
+    }
+    if (wave == 0) {
+        const uint32_t p = lane < BF_ROWS ? mine[lane].pos : POS_SENTINEL;
+        if (lane < BF_ROWS) sh_pos[lane] = p;
+        const unsigned long long real = __ballot(p != POS_SENTINEL);  // sorted list: the real entries come first
+        if (lane == 0) sh_n = __popcll(real);
+    }
+    __syncthreads();
+    const int n_mine = sh_n;
+    Acc64<METRIC> A;
+    rescore_rows_par<METRIC, BF_ROWS, 256>(master, q64, dim, sh_pos, n_mine, rs, A, q_first);
+    if (wave == 0 && lane < BF_ROWS) scores[(size_t)q * KP + quarter * BF_ROWS + lane] = lane < n_mine ? A.score() : 0.0;
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void k_batch_rank_emit(const Cand32* __restrict__ lists, const double* __restrict__ scores,
+                                                         const double* __restrict__ q_norms, uint32_t nq, uint32_t ld,
+                                                         uint64_t n_rows, uint32_t k, double R, double in_extra,
+                                                         SearchResultBlock* __restrict__ out, ShardRecordSink sink)
+{
+    const int lane = lane_id();
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const Cand32 e = lists[(size_t)q * KP + lane];
+    const int n_cand = __popcll(__ballot(e.pos != POS_SENTINEL));
+    const double sc = lane < n_cand ? scores[(size_t)q * KP + lane] : 0.0;
+    rank_check_emit<METRIC>(sc, e.pos, read_lane(e.key, KP - 1), n_cand, k, n_rows, ld, R, q_norms[q], in_extra, out + q, 0u, sink, q);
+}
+
 // K2: merge partial lists, rescore, rank, bound-check.  One workgroup of 1024 threads.
 template <int METRIC>
 __global__ __launch_bounds__(1024) void k_merge_finalize(const Cand32* __restrict__ partials, int n_lists,
@@ -606,7 +739,7 @@ __global__ __launch_bounds__(1024) void k_merge_finalize(const Cand32* __restric
     VL_STAMP(0);
     // phase 1: n_lists <= 64 sorted lists: up to 16 waves x 4 bitonic folds, then a tree merge over the waves that hold one
     TopList<float> L;
-    double q_first = 0.0;
+    double q_first[1] = {0.0};
     {
         const int first = wave * 4;
         int count = n_lists - first;
@@ -615,7 +748,7 @@ __global__ __launch_bounds__(1024) void k_merge_finalize(const Cand32* __restric
         fold_lists4_load<Cand32>(e, partials, first, count);
         // the query's first block is requested BEHIND the list loads (vector loads return in order: in front of
         // them the wave would sit out the pinned-memory round trip before it can merge) and is consumed only in phase 2
-        if (threadIdx.x < RP_BW) q_first = q64[threadIdx.x < dim ? threadIdx.x : dim - 1];
+        if (threadIdx.x < RP_BW) q_first[0] = q64[threadIdx.x < dim ? threadIdx.x : dim - 1];
         fold_lists4_merge<float, Cand32>(L, e, count);
     }
     VL_STAMP(1);
@@ -633,70 +766,14 @@ __global__ __launch_bounds__(1024) void k_merge_finalize(const Cand32* __restric
     // phase 2: exact f64 rescoring of the candidates
     Acc64<METRIC> A;
     VL_STAMP(3);
-    rescore_rows_par<METRIC>(master, q64, dim, sh_pos, n_cand, rs, A, q_first);
+    rescore_rows_par<METRIC, KP, 1024>(master, q64, dim, sh_pos, n_cand, rs, A, q_first);
     VL_STAMP(8);
 
     // phase 3: rank by (score desc, pos asc), bound check, emit
     if (wave == 0) {
         const bool valid = lane < n_cand;
         const double sc = valid ? A.score() : 0.0;
-        const uint32_t my_pos = sh_pos[lane];
-        const bool any_nan = __ballot(valid && sc != sc) != 0ull;
-        // rank = how many candidates stand in front of this one: every candidate sits in a lane of this wave, so
-        // entry j is read with v_readlane (a scalar operand of the compares), no LDS round trip per entry
-        int rank = 0;
-        for (int j = 0; j < n_cand; ++j) {
-            const double sj = read_lane(sc, j);
-            const uint32_t pj = read_lane(my_pos, j);
-            rank += (sj > sc || (sj == sc && pj < my_pos)) ? 1 : 0;
-        }
-        const uint32_t k_eff = (uint64_t)k < n_rows ? k : (uint32_t)n_rows;
-        uint32_t flags = 0;
-        if (any_nan) flags |= RESULT_HAS_NAN | RESULT_NEEDS_EXACT;
-        if (n_rows <= (uint64_t)KP) {
-            // the list must hold EVERY row; a shorter one (a candidate stage that overflowed or dropped rows)
-            // proves nothing
-            if ((uint64_t)n_cand < n_rows) flags |= RESULT_NEEDS_EXACT;
-        } else {
-            // rows outside the candidate list exist: all of them have scan key <= the 64th key
-            if (n_cand < KP) {
-                flags |= RESULT_NEEDS_EXACT;  // keys were not finite: outside the fast-path domain
-            } else {
-                const double B = bound_for_key<METRIC>(sh_key[KP - 1], ld, R, Q, in_extra);
-                // score of the entry ranked k_eff-1
-                const unsigned long long at_cut = __ballot(valid && rank == (int)k_eff - 1);
-                double s_cut = 0.0;
-                if (at_cut) s_cut = __shfl(sc, __ffsll((long long)at_cut) - 1);
-                if (!at_cut || !(s_cut > B)) flags |= RESULT_NEEDS_EXACT;
-            }
-        }
-        if (valid && rank < (int)k_eff) {
-            out->pos[rank] = my_pos;
-            out->score[rank] = sc;
-        }
-        if (lane == 0) {
-            out->n_out = k_eff;
-            out->flags = flags;
-        }
-        if (sink.cnt) {  // a row shard's exchange record, written where the all-gather reads it (shard.hpp)
-            const uint32_t q = sink.q0 + blockIdx.x;
-            const uint32_t offered = (flags == 0u) ? (k_eff < sink.ks ? k_eff : sink.ks) : 0u;  // not certified: the host redoes it
-            if (valid && (uint32_t)rank < offered) {
-                const size_t e = (size_t)q * sink.ks + (uint32_t)rank;
-                sink.score_bits[e] = (unsigned long long)__double_as_longlong(sc);
-                sink.gpos[e] = sink.row_offset + (unsigned long long)my_pos;
-                sink.ids[e] = sink.pos_to_id[my_pos];
-            }
-            if (lane == 0) sink.cnt[q] = offered;
-        }
-        VL_STAMP(9);
-        if (seq) {
-            // the host spins on out->seq (pinned memory): every lane's stores of the block above are complete at
-            // system scope before the stamp leaves (wave 0 is the only writer of the block)
-            __threadfence_system();
-            if (lane == 0) __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        VL_STAMP(10);
+        rank_check_emit<METRIC>(sc, sh_pos[lane], sh_key[KP - 1], n_cand, k, n_rows, ld, R, Q, in_extra, out, seq, sink, blockIdx.x);
     }
 }
 
@@ -729,8 +806,8 @@ __global__ __launch_bounds__(1024) void k_merge_finalize_multi(const Cand32* __r
     const double Q = q_norms[0];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
-    double q_first = 0.0;
-    if (threadIdx.x < RP_BW) q_first = q64[threadIdx.x < dim ? threadIdx.x : dim - 1];
+    double q_first[1] = {0.0};
+    if (threadIdx.x < RP_BW) q_first[0] = q64[threadIdx.x < dim ? threadIdx.x : dim - 1];
     if (threadIdx.x == 0) {
         sh_flags = 0;
         sh_has_cut = 0;
@@ -755,7 +832,7 @@ __global__ __launch_bounds__(1024) void k_merge_finalize_multi(const Cand32* __r
     // phase 2: exact f64 rescoring, 64 rows at a time through the same LDS tile
     for (int p = 0; p < n_parts; ++p) {
         Acc64<METRIC> A;
-        rescore_rows_par<METRIC>(master, q64, dim, sh_pos + p * KP, sh_ncand[p], rs, A, q_first);
+        rescore_rows_par<METRIC, KP, 1024>(master, q64, dim, sh_pos + p * KP, sh_ncand[p], rs, A, q_first);
         if (wave == 0) sh_score[p * KP + lane] = lane < sh_ncand[p] ? A.score() : 0.0;
         __syncthreads();
     }
@@ -1529,6 +1606,22 @@ hipError_t launch_merge_finalize(hipStream_t s, int metric, Cand32* partials, in
         constexpr int MM = decltype(M)::value;
         hipLaunchKernelGGL((k_merge_finalize<MM>), dim3(nq), dim3(1024), 0, s, lists, n_lists, stride, master, q64,
                            q_norms, dim, ld, n_rows, k, max_row_norm, in_extra, out, seq, sk);
+        return hipGetLastError();
+    });
+}
+
+hipError_t launch_batch_finalize(hipStream_t s, int metric, const Cand32* lists, int nq, const double* master, const double* q64,
+                                 const double* q_norms, uint32_t dim, uint64_t n_rows, uint32_t k, double max_row_norm,
+                                 SearchResultBlock* out, double in_extra, double* score_scratch, const ShardRecordSink* sink)
+{
+    if (nq <= 0 || !score_scratch) return hipErrorInvalidValue;
+    const uint32_t ld = (dim + 3u) & ~3u;
+    const ShardRecordSink sk = sink ? *sink : ShardRecordSink{};
+    return dispatch_metric(metric, [&](auto M) -> hipError_t {
+        constexpr int MM = decltype(M)::value;
+        hipLaunchKernelGGL((k_batch_rescore<MM>), dim3((unsigned)nq * 4u), dim3(256), 0, s, lists, master, q64, dim, score_scratch);
+        hipLaunchKernelGGL((k_batch_rank_emit<MM>), dim3(((unsigned)nq + 3u) / 4u), dim3(256), 0, s, lists, (const double*)score_scratch,
+                           q_norms, (uint32_t)nq, ld, n_rows, k, max_row_norm, in_extra, out, sk);
         return hipGetLastError();
     });
 }

@@ -124,6 +124,15 @@ hipError_t launch_merge_finalize(hipStream_t s, int metric, Cand32* partials, in
                                  uint64_t n_rows, uint32_t k, double max_row_norm, SearchResultBlock* out,
                                  double in_extra = 0.0, uint32_t seq = 0, const ShardRecordSink* sink = nullptr);
 
+// K2 for a batch whose candidates already are ONE sorted top-64 list per query (lists[nq][KP], the MFMA filter's output):
+// the rescoring of each query's 64 rows split over four 256-thread workgroups + one wave per query that ranks, checks the
+// bound and emits -- the same arithmetic and result blocks as launch_merge_finalize(n_lists = 1), at batch throughput.
+// score_scratch: nq x KP doubles of device memory.
+hipError_t launch_batch_finalize(hipStream_t s, int metric, const Cand32* lists, int nq, const double* master, const double* q64,
+                                 const double* q_norms, uint32_t dim, uint64_t n_rows, uint32_t k, double max_row_norm,
+                                 SearchResultBlock* out, double in_extra, double* score_scratch,
+                                 const ShardRecordSink* sink = nullptr);
+
 // K3: one slab pass for nq <= SCAN_BATCH_QB queries (q64 is [nq, dim]); lists are written query-major.
 bool scan_batch_supported(uint32_t ld);
 hipError_t launch_scan_batch(hipStream_t s, int metric, const float* slab, const float* inv_norm, const double* q64,
