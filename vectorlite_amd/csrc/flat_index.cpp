@@ -88,10 +88,10 @@ Workspace::~Workspace()
                    d_opos, d_out_pos, d_out_scores, d_positions, d_dists};
     for (void* p : dev)
         if (p) (void)hipFree(p);
-    void* host[] = {h_q64, h_result, h_nan, mf_h_q64, mf_h_result, mf_h_dom};
+    void* host[] = {h_q64, h_result, h_nan, mf_h_q64, mf_h_result, mf_h_dom, k3_h_q64, k3_h_result};
     for (void* p : host)
         if (p) (void)hipHostFree(p);
-    void* mfd[] = {mf.q_bf16, mf.gmax, mf.thr, mf.cand, mf.cnt, mf_d_q64, mf_lists, mf_scores};
+    void* mfd[] = {mf.q_bf16, mf.gmax, mf.thr, mf.cand, mf.cnt, mf_d_q64, mf_lists, mf_scores, k3_d_q64};
     for (void* p : mfd)
         if (p) (void)hipFree(p);
     if (ev0) (void)hipEventDestroy(ev0);
@@ -798,37 +798,49 @@ int GpuFlatIndex::search_batch_locked(const double* queries, uint64_t nq, uint64
         if (!done[qi]) todo.push_back(qi);
     const uint64_t nt = todo.size();
     const bool prof = profile_.load();
-    for (uint64_t q0 = 0; q0 < nt; q0 += SCAN_BATCH_QB) {
-        const uint32_t g = (uint32_t)std::min<uint64_t>(SCAN_BATCH_QB, nt - q0);
-        bool in_domain[SCAN_BATCH_QB];
-        double* norms = ws->h_q64 + (size_t)g * dim_;
-        for (uint32_t j = 0; j < g; ++j)
-            in_domain[j] = stage_query(queries + todo[q0 + j] * dim_, ws->h_q64 + (size_t)j * dim_, dim_, &norms[j]);
-        VL_HIP(hipMemcpyAsync(ws->d_q64, ws->h_q64, ((size_t)g * dim_ + g) * sizeof(double), hipMemcpyHostToDevice, st));
-        ScanPlan plan;
+    // Up to K3_PIPE_QUERIES queries are staged at once (one H2D copy), their passes of 8 are enqueued back to back --
+    // scan, list merge, finalize, the next scan ...: stream order lets every pass reuse the one partial-list buffer -- and the
+    // stream is synchronised ONCE: staged, launched and synchronised pass by pass a 50 000-row index answered 70-100 k
+    // Manhattan queries per second where cosine batches reach millions (round 3's verdict, item 8).
+    if (!ws->k3_d_q64) {
+        const size_t words = (size_t)K3_PIPE_QUERIES * (dim_ + 1);
+        VL_TRY(dev_alloc(&ws->k3_d_q64, words));
+        VL_TRY(pinned_alloc(&ws->k3_h_q64, words));
+        VL_TRY(pinned_alloc(&ws->k3_h_result, (size_t)K3_PIPE_QUERIES));
+    }
+    std::vector<uint8_t> in_domain((size_t)K3_PIPE_QUERIES);
+    for (uint64_t base = 0; base < nt; base += K3_PIPE_QUERIES) {
+        const uint32_t cnt = (uint32_t)std::min<uint64_t>(K3_PIPE_QUERIES, nt - base);
+        double* norms = ws->k3_h_q64 + (size_t)cnt * dim_;
+        for (uint32_t j = 0; j < cnt; ++j)
+            in_domain[j] = stage_query(queries + todo[base + j] * dim_, ws->k3_h_q64 + (size_t)j * dim_, dim_, &norms[j]) ? 1 : 0;
+        VL_HIP(hipMemcpyAsync(ws->k3_d_q64, ws->k3_h_q64, ((size_t)cnt * dim_ + cnt) * sizeof(double), hipMemcpyHostToDevice, st));
+        const double* d_norms = ws->k3_d_q64 + (size_t)cnt * dim_;
+        uint32_t passes = 0;
         if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
-        VL_HIP(launch_scan_batch(st, metric, d_slab_, d_inv_norm_, ws->d_q64, g, n, (uint32_t)dim_, ld_, ws->d_partials,
-                                 &plan));
+        for (uint32_t q0 = 0; q0 < cnt; q0 += SCAN_BATCH_QB) {
+            const uint32_t g = std::min<uint32_t>(SCAN_BATCH_QB, cnt - q0);
+            ScanPlan plan;
+            VL_HIP(launch_scan_batch(st, metric, d_slab_, d_inv_norm_, ws->k3_d_q64 + (size_t)q0 * dim_, g, n, (uint32_t)dim_, ld_,
+                                     ws->d_partials, &plan));
+            VL_HIP(launch_merge_finalize(st, metric, ws->d_partials, plan.grid, (int)g, d_master_, ws->k3_d_q64 + (size_t)q0 * dim_,
+                                         d_norms + q0, (uint32_t)dim_, n, (uint32_t)k_eff, max_row_norm_, ws->k3_h_result + q0));
+            ++passes;
+        }
         if (prof) VL_HIP(hipEventRecord(ws->ev1, st));
-        VL_HIP(launch_merge_finalize(st, metric, ws->d_partials, plan.grid, (int)g, d_master_, ws->d_q64,
-                                     ws->d_q64 + (size_t)g * dim_, (uint32_t)dim_, n, (uint32_t)k_eff, max_row_norm_,
-                                     ws->h_result));
         VL_HIP(hipStreamSynchronize(st));
-        if (prof) {
+        if (prof) {  // (with several passes in flight the events bracket scans AND finalizes of the group: an upper bound per pass)
             float ms = 0.f;
             VL_HIP(hipEventElapsedTime(&ms, ws->ev0, ws->ev1));
             std::lock_guard<std::mutex> gl(prof_mu_);
-            prof_n_ += 1;
+            prof_n_ += passes;
             prof_ms_ += ms;
-            prof_bytes_ += n * (uint64_t)ld_ * sizeof(float);
+            prof_bytes_ += (uint64_t)passes * n * (uint64_t)ld_ * sizeof(float);
         }
-        // copy the result blocks out first: a fallback below reuses the workspace
-        SearchResultBlock blocks[SCAN_BATCH_QB];
-        std::memcpy(blocks, ws->h_result, g * sizeof(SearchResultBlock));
-        for (uint32_t j = 0; j < g; ++j) {
-            const uint64_t qi = todo[q0 + j];
-            const SearchResultBlock& r = blocks[j];
-            bool ok = in_domain[j] && !(r.flags & RESULT_NEEDS_EXACT) && r.n_out == k_eff;
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const uint64_t qi = todo[base + j];
+            const SearchResultBlock& r = ws->k3_h_result[j];  // (a fallback below uses the workspace's other buffers, not these)
+            const bool ok = in_domain[j] && !(r.flags & RESULT_NEEDS_EXACT) && r.n_out == k_eff;
             if (ok) {
                 for (uint64_t i = 0; i < k_eff; ++i) {
                     const uint32_t p = r.pos[i];

@@ -38,6 +38,7 @@ enum Status : int {
     ERR_INVALID_ARG = 8,
 };
 
+constexpr int K3_PIPE_QUERIES = 512;  // queries whose 8-query f32 slab passes are enqueued back to back before one stream sync
 constexpr int COALESCE_DEFAULT_BATCH = 256;  // concurrent callers one pass answers at most, by default (window 0)
 
 enum Path : int { PATH_NONE = 0, PATH_FAST = 1, PATH_EXACT_SELECT = 2, PATH_EXACT_SORT = 3 };
@@ -80,6 +81,10 @@ struct Workspace {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<float> q32;   // the f32 query handed to k_scan in its kernel arguments
     uint32_t seq = 0;         // stamp of the last single search issued from this workspace (h_result->seq)
+    // f32 batch path (K3), several passes in flight: staging for K3_PIPE_QUERIES queries and their result blocks (lazy)
+    double* k3_d_q64 = nullptr;                // [K3_PIPE_QUERIES, dim] queries, then their norms
+    double* k3_h_q64 = nullptr;                // pinned
+    SearchResultBlock* k3_h_result = nullptr;  // pinned [K3_PIPE_QUERIES]
     // large-batch MFMA path (lazy)
     MfmaScratch mf;
     double* mf_d_q64 = nullptr;             // [MFMA_MAX_BATCH, dim] queries, then their norms
