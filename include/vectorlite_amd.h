@@ -417,6 +417,11 @@ int vl_index_profile_read(vl_index *h, uint64_t *n_scan_launches, double *scan_m
  * on, and whether the query travelled in the kernel arguments.  bench.py ties its PMC traffic figure to these. */
 int vl_index_last_scan(const vl_index *h, int *variant, int *grid, int *query_in_kernarg);
 
+/* The last launch sequence of the batch filter (bf16 MFMA, k_mfma_rows) on this handle, out6 = {K steps of 16 (row stride
+ * / 16), metric, query chunks, workgroups per chunk of the last pass-1 stage, pass-1 stages, 32-row blocks sampled}; all
+ * zero before the first such batch.  bench.py ties the PMC traffic figures of configs 3 and 5 to these. */
+int vl_index_last_filter(const vl_index *h, int *out6);
+
 /* Library/version probe; also reports how many HIP devices are visible (0 -> no GPU). */
 int vl_runtime_info(int *n_devices, int *abi_version);
 

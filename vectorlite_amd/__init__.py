@@ -478,6 +478,12 @@ class FlatIndex:
         _raise(self._L.vl_index_last_scan(self._h, C.byref(v), C.byref(g), C.byref(q)))
         return {"variant": int(v.value), "grid": int(g.value), "query_in_kernarg": int(q.value)}
 
+    def last_filter(self) -> Dict[str, int]:
+        """The batch filter's last launch sequence on this handle (vl_index_last_filter)."""
+        v = (C.c_int * 6)()
+        _raise(self._L.vl_index_last_filter(self._h, v))
+        return {"ksteps": v[0], "metric": v[1], "chunks": v[2], "grid_x": v[3], "stages": v[4], "sample_blocks": v[5]}
+
     def profile_enable(self, on: bool) -> None:
         _raise(self._L.vl_index_profile_enable(self._h, 1 if on else 0))
 

@@ -22,7 +22,7 @@ SYMBOLS = [
     "vl_last_error", "vl_last_dim_mismatch", "vl_last_path", "vl_index_force_path", "vl_index_set_single_filter",
     "vl_index_set_coalescing", "vl_index_coalesce_stats", "vl_index_hnsw_walk_stats",
     "vl_vlc_open", "vl_vlc_close", "vl_vlc_name", "vl_vlc_info", "vl_vlc_side_table", "vl_vlc_read_values", "vl_vlc_build_index",
-    "vl_index_profile_enable", "vl_index_profile_read", "vl_index_last_scan", "vl_runtime_info",
+    "vl_index_profile_enable", "vl_index_profile_read", "vl_index_last_scan", "vl_index_last_filter", "vl_runtime_info",
     "vl_comm_unique_id", "vl_comm_create", "vl_comm_destroy", "vl_comm_world", "vl_comm_rank", "vl_comm_profile_enable", "vl_comm_profile_read", "vl_comm_record_paths",
     "vl_index_hnsw_set_min_beam", "vl_index_hnsw_graph_info", "vl_index_hnsw_graph_export",
     "vl_shard_sync", "vl_shard_search_batch", "vl_shard_packed_words", "vl_shard_search_local", "vl_shard_merge", "vl_shard_search_batch_dev", "vl_shard_search_local_dev",
@@ -111,6 +111,7 @@ def load() -> C.CDLL:
     sig("vl_index_profile_enable", i32, [vp, i32])
     sig("vl_index_profile_read", i32, [vp, p_u64, p_f64, p_u64])
     sig("vl_index_last_scan", i32, [vp, p_i32, p_i32, p_i32])
+    sig("vl_index_last_filter", i32, [vp, p_i32])
     sig("vl_runtime_info", i32, [C.POINTER(C.c_int), C.POINTER(C.c_int)])
     p_u8 = C.POINTER(C.c_uint8)
     sig("vl_comm_unique_id", i32, [p_u8])

@@ -838,6 +838,12 @@ int vl_index_last_scan(const vl_index* h, int* variant, int* grid, int* query_in
     return on_flat(h, [&](auto* f) { f->last_scan(variant, grid, query_in_kernarg); return (int)VL_OK; });
 }
 
+int vl_index_last_filter(const vl_index* h, int* out6)
+{
+    if (!h || h->hnsw || !out6) return VL_ERR_INVALID_ARG;
+    return on_flat(h, [&](auto* f) { f->last_filter(out6); return (int)VL_OK; });
+}
+
 int vl_index_profile_enable(vl_index* h, int enable)
 {
     if (!h || h->hnsw) return VL_ERR_INVALID_ARG;

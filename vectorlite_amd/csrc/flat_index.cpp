@@ -798,10 +798,10 @@ int GpuFlatIndex::search_batch_locked(const double* queries, uint64_t nq, uint64
         if (!done[qi]) todo.push_back(qi);
     const uint64_t nt = todo.size();
     const bool prof = profile_.load();
-    // Up to K3_PIPE_QUERIES queries are staged at once (one H2D copy), their passes of 8 are enqueued back to back --
-    // scan, list merge, finalize, the next scan ...: stream order lets every pass reuse the one partial-list buffer -- and the
-    // stream is synchronised ONCE: staged, launched and synchronised pass by pass a 50 000-row index answered 70-100 k
-    // Manhattan queries per second where cosine batches reach millions (round 3's verdict, item 8).
+    // Up to K3_PIPE_QUERIES queries are staged at once (one H2D copy) and answered by ONE scan launch -- their groups of 8 as
+    // blockIdx.y, each group one pass over the slab -- and ONE finalize launch, then one stream sync: staged, launched and
+    // synchronised pass by pass a 50 000-row index answered 70-100 k Manhattan queries per second where cosine batches
+    // reach millions (round 3's verdict, item 8).
     if (!ws->k3_d_q64) {
         const size_t words = (size_t)K3_PIPE_QUERIES * (dim_ + 1);
         VL_TRY(dev_alloc(&ws->k3_d_q64, words));
@@ -816,20 +816,17 @@ int GpuFlatIndex::search_batch_locked(const double* queries, uint64_t nq, uint64
             in_domain[j] = stage_query(queries + todo[base + j] * dim_, ws->k3_h_q64 + (size_t)j * dim_, dim_, &norms[j]) ? 1 : 0;
         VL_HIP(hipMemcpyAsync(ws->k3_d_q64, ws->k3_h_q64, ((size_t)cnt * dim_ + cnt) * sizeof(double), hipMemcpyHostToDevice, st));
         const double* d_norms = ws->k3_d_q64 + (size_t)cnt * dim_;
-        uint32_t passes = 0;
+        const uint32_t passes = (cnt + SCAN_BATCH_QB - 1) / SCAN_BATCH_QB;
         if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
-        for (uint32_t q0 = 0; q0 < cnt; q0 += SCAN_BATCH_QB) {
-            const uint32_t g = std::min<uint32_t>(SCAN_BATCH_QB, cnt - q0);
+        {   // ONE scan launch (groups of 8 queries as blockIdx.y: each group is one pass over the slab) and ONE finalize launch
             ScanPlan plan;
-            VL_HIP(launch_scan_batch(st, metric, d_slab_, d_inv_norm_, ws->k3_d_q64 + (size_t)q0 * dim_, g, n, (uint32_t)dim_, ld_,
-                                     ws->d_partials, &plan));
-            VL_HIP(launch_merge_finalize(st, metric, ws->d_partials, plan.grid, (int)g, d_master_, ws->k3_d_q64 + (size_t)q0 * dim_,
-                                         d_norms + q0, (uint32_t)dim_, n, (uint32_t)k_eff, max_row_norm_, ws->k3_h_result + q0));
-            ++passes;
+            VL_HIP(launch_scan_batch(st, metric, d_slab_, d_inv_norm_, ws->k3_d_q64, cnt, n, (uint32_t)dim_, ld_, ws->d_partials, &plan));
+            VL_HIP(launch_merge_finalize(st, metric, ws->d_partials, plan.grid, (int)cnt, d_master_, ws->k3_d_q64, d_norms,
+                                         (uint32_t)dim_, n, (uint32_t)k_eff, max_row_norm_, ws->k3_h_result));
         }
         if (prof) VL_HIP(hipEventRecord(ws->ev1, st));
         VL_HIP(hipStreamSynchronize(st));
-        if (prof) {  // (with several passes in flight the events bracket scans AND finalizes of the group: an upper bound per pass)
+        if (prof) {  // (the events bracket the one scan launch: `passes` slab passes side by side)
             float ms = 0.f;
             VL_HIP(hipEventElapsedTime(&ms, ws->ev0, ws->ev1));
             std::lock_guard<std::mutex> gl(prof_mu_);
@@ -1422,8 +1419,13 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, const 
         }
         const auto t_1 = now();
         if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
+        MfmaLaunchInfo li;
         VL_HIP(launch_mfma_candidates(st, metric, slab16, d_norm16_, d_sqnorm_, ws->mf_d_q64, g, n, (uint32_t)dim_,
-                                      ws->mf, ws->mf_lists));
+                                      ws->mf, ws->mf_lists, &li));
+        {
+            const int v[6] = {li.ksteps, li.metric, li.chunks, li.grid_x, li.stages, li.sample_blocks};
+            for (int i = 0; i < 6; ++i) last_filter_[i].store(v[i], std::memory_order_relaxed);
+        }
         if (prof) VL_HIP(hipEventRecord(ws->ev1, st));
         ShardRecordSink seq_sink;
         if (sink) {  // this sequence's queries sit at [q0, q0 + g) of the record

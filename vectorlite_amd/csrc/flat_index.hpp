@@ -38,7 +38,7 @@ enum Status : int {
     ERR_INVALID_ARG = 8,
 };
 
-constexpr int K3_PIPE_QUERIES = 512;  // queries whose 8-query f32 slab passes are enqueued back to back before one stream sync
+constexpr int K3_PIPE_QUERIES = SCAN_BATCH_MAX_QUERIES;  // queries staged, launched (one scan + one finalize) and synchronised together on the f32 batch path
 constexpr int COALESCE_DEFAULT_BATCH = 256;  // concurrent callers one pass answers at most, by default (window 0)
 
 enum Path : int { PATH_NONE = 0, PATH_FAST = 1, PATH_EXACT_SELECT = 2, PATH_EXACT_SORT = 3 };
@@ -204,6 +204,12 @@ public:
         if (grid) *grid = last_scan_grid_.load();
         if (qarg) *qarg = last_scan_qarg_.load();
     }
+    // the batch filter's last launch sequence on this handle: {K steps of 16, metric, query chunks, workgroups per chunk of
+    // the last pass-1 stage, pass-1 stages, 32-row blocks sampled}; all zero before the first MFMA batch
+    void last_filter(int out[6]) const
+    {
+        for (int i = 0; i < 6; ++i) out[i] = last_filter_[i].load(std::memory_order_relaxed);
+    }
     int device() const { return device_; }
 
 private:
@@ -286,6 +292,7 @@ private:
     static constexpr int SPIN_MAX_MS = 200;
     mutable std::atomic<int> active_searches_{0};
     mutable std::atomic<int> last_scan_variant_{0}, last_scan_grid_{0}, last_scan_qarg_{0};
+    mutable std::atomic<int> last_filter_[6] = {};
     mutable std::mutex prof_mu_;
     mutable uint64_t prof_n_ = 0;
     mutable double prof_ms_ = 0.0;

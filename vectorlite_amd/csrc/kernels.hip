@@ -277,6 +277,14 @@ __global__ __launch_bounds__(256) void k_scan_batch(const f32x4* __restrict__ sl
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const int g = lane / G, c = lane % G;
+    // blockIdx.y = a group of QB queries: groups share nothing but the slab (one launch answers up to gridDim.y * QB queries;
+    // on a small index that is what keeps the chip busy -- one group's pass is a few workgroups)
+    {
+        const uint32_t first = blockIdx.y * QB;
+        q64 += (size_t)first * dim;
+        out += (size_t)first * gridDim.x * KP;
+        n_q = n_q - first < (uint32_t)QB ? n_q - first : (uint32_t)QB;
+    }
 
     for (uint32_t idx = threadIdx.x; idx < QB * LD4; idx += 256) {
         const uint32_t qi = idx / LD4, j = idx % LD4;
@@ -426,28 +434,29 @@ constexpr int RP_CH = 48;               // columns per LDS tile (row stride 49 d
 constexpr int RP_NCH = 8;               // tiles per block of columns fetched from HBM together
 constexpr int RP_BW = RP_CH * RP_NCH;   // 384 columns: one memory round trip for a dim-384 row
 
-template <int METRIC, int ROWS = KP>
+template <int METRIC, int ROWS = KP, int NCH = RP_NCH>
 struct RescoreLds {
     double tA[ROWS][RP_CH + 1];                                 // the summands of `a`
     double tB[METRIC == COSINE ? ROWS : 1][RP_CH + 1];          // cosine: x * x
-    double qblk[RP_BW];                                         // the query's columns of the current block
-    double qq[METRIC == COSINE ? RP_BW : 1];                    // cosine: y * y
+    double qblk[RP_CH * NCH];                                   // the query's columns of the current block
+    double qq[METRIC == COSINE ? RP_CH * NCH : 1];              // cosine: y * y
     double b[ROWS];
     double c;
 };
 
 // ROWS candidate rows rescored by a workgroup of NTHREADS threads (ROWS * RP_CH tile elements, RP_PER per thread):
 // 64 rows x 1024 threads for a single search's finalize, 16 rows x 256 threads for a quarter of a batch query's list.
-template <int METRIC, int ROWS, int NTHREADS>
+template <int METRIC, int ROWS, int NTHREADS, int NCH = RP_NCH>
 __device__ __forceinline__ void rescore_rows_par(const double* __restrict__ master, const double* __restrict__ q64,
                                                  uint32_t dim, const uint32_t* sh_pos, int n_rows,
-                                                 RescoreLds<METRIC, ROWS>& S, Acc64<METRIC>& A,
-                                                 const double (&q_first)[(RP_BW + NTHREADS - 1) / NTHREADS])
+                                                 RescoreLds<METRIC, ROWS, NCH>& S, Acc64<METRIC>& A,
+                                                 const double (&q_first)[(RP_CH * NCH + NTHREADS - 1) / NTHREADS])
 {
     // q_first[j]: q64[min(tid + j NTHREADS, dim - 1)], fetched by the caller at kernel entry (a single search reads
     // its query from pinned host memory: that PCIe round trip then hides behind the list merge)
     constexpr int RP_PER = ROWS * RP_CH / NTHREADS;
-    constexpr int QN = (RP_BW + NTHREADS - 1) / NTHREADS;
+    constexpr int BW = RP_CH * NCH;  // columns fetched from HBM together (one memory round trip)
+    constexpr int QN = (BW + NTHREADS - 1) / NTHREADS;
     static_assert(ROWS * RP_CH % NTHREADS == 0 && ROWS <= WAVE, "tile elements divide evenly; one lane per row");
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1), wave = tid >> 6;
@@ -455,10 +464,10 @@ __device__ __forceinline__ void rescore_rows_par(const double* __restrict__ mast
     if (n_rows <= 0) return;  // workgroup-uniform (an all-sentinel candidate list)
     // what this thread accumulates: wave 0 the rows' `a`, wave 1 their `b`, wave 2 the query's `c` (cosine)
     double acc = (METRIC == COSINE) ? 0.0 : -0.0;
-    for (uint32_t g0 = 0; g0 < dim; g0 += RP_BW) {
-        double pre[RP_NCH][RP_PER];
+    for (uint32_t g0 = 0; g0 < dim; g0 += BW) {
+        double pre[NCH][RP_PER];
 #pragma unroll
-        for (int p = 0; p < RP_NCH; ++p) {
+        for (int p = 0; p < NCH; ++p) {
             const uint32_t c0 = g0 + p * RP_CH;
 #pragma unroll
             for (int i = 0; i < RP_PER; ++i) {
@@ -476,7 +485,7 @@ __device__ __forceinline__ void rescore_rows_par(const double* __restrict__ mast
 #pragma unroll
         for (int j = 0; j < QN; ++j) {
             qv[j] = q_first[j];
-            if (g0 != 0 && tid + j * NTHREADS < RP_BW) {
+            if (g0 != 0 && tid + j * NTHREADS < BW) {
                 const uint32_t col = g0 + (uint32_t)(tid + j * NTHREADS);
                 qv[j] = q64[col < dim ? col : dim - 1];
             }
@@ -485,14 +494,14 @@ __device__ __forceinline__ void rescore_rows_par(const double* __restrict__ mast
         __syncthreads();  // the previous block's qblk / tiles are consumed
 #pragma unroll
         for (int j = 0; j < QN; ++j)
-            if (tid + j * NTHREADS < RP_BW) {
+            if (tid + j * NTHREADS < BW) {
                 S.qblk[tid + j * NTHREADS] = qv[j];
                 if (METRIC == COSINE) S.qq[tid + j * NTHREADS] = qv[j] * qv[j];
             }
         __syncthreads();
         VL_STAMP(5);
 #pragma unroll
-        for (int p = 0; p < RP_NCH; ++p) {
+        for (int p = 0; p < NCH; ++p) {
             const uint32_t c0 = g0 + p * RP_CH;
             if (c0 >= dim) break;  // workgroup-uniform
             const uint32_t cw = (dim - c0) < (uint32_t)RP_CH ? (dim - c0) : (uint32_t)RP_CH;
@@ -665,18 +674,23 @@ __device__ __forceinline__ void rank_check_emit(double sc, uint32_t my_pos, floa
 // so some load while others add), and a second launch of one wave per query ranks, checks the bound and emits.  Same
 // arithmetic, same order: per row, products by all threads, one lane adds them in index order.
 constexpr int BF_ROWS = 16;
+#ifndef VL_BF_NCH
+#define VL_BF_NCH 4
+#endif
+constexpr int BF_NCH = VL_BF_NCH;  // 48-column tiles fetched together: 4 = 192 columns in flight per thread (24 registers of row
+                                   // data, 8 workgroups per CU); 8 = a dim-384 row in one round trip but 104 registers = 4 per CU
 template <int METRIC>
 __global__ __launch_bounds__(256) void k_batch_rescore(const Cand32* __restrict__ lists, const double* __restrict__ master,
                                                        const double* __restrict__ q64, uint32_t dim, double* __restrict__ scores)
 {
     const uint32_t q = blockIdx.x >> 2, quarter = blockIdx.x & 3u;
-    __shared__ RescoreLds<METRIC, BF_ROWS> rs;
+    __shared__ RescoreLds<METRIC, BF_ROWS, BF_NCH> rs;
     __shared__ uint32_t sh_pos[BF_ROWS];
     __shared__ int sh_n;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     const Cand32* mine = lists + (size_t)q * KP + quarter * BF_ROWS;
     q64 += (size_t)q * dim;
-    constexpr int QN = (RP_BW + 255) / 256;
+    constexpr int QN = (RP_CH * BF_NCH + 255) / 256;
     double q_first[QN];
 #pragma unroll
     for (int j = 0; j < QN; ++j) {
@@ -692,7 +706,7 @@ __global__ __launch_bounds__(256) void k_batch_rescore(const Cand32* __restrict_
     __syncthreads();
     const int n_mine = sh_n;
     Acc64<METRIC> A;
-    rescore_rows_par<METRIC, BF_ROWS, 256>(master, q64, dim, sh_pos, n_mine, rs, A, q_first);
+    rescore_rows_par<METRIC, BF_ROWS, 256, BF_NCH>(master, q64, dim, sh_pos, n_mine, rs, A, q_first);
     if (wave == 0 && lane < BF_ROWS) scores[(size_t)q * KP + quarter * BF_ROWS + lane] = lane < n_mine ? A.score() : 0.0;
 }
 
@@ -1531,10 +1545,11 @@ bool scan_batch_supported(uint32_t ld)
 hipError_t launch_scan_batch(hipStream_t s, int metric, const float* slab, const float* inv_norm, const double* q64,
                              uint32_t nq, uint64_t n, uint32_t dim, uint32_t ld, Cand32* partials, ScanPlan* plan)
 {
-    if (n == 0 || n >= 0xFFFFFFFFull || (ld & 3) || nq == 0 || nq > (uint32_t)SCAN_BATCH_QB) return hipErrorInvalidValue;
+    if (n == 0 || n >= 0xFFFFFFFFull || (ld & 3) || nq == 0 || nq > (uint32_t)SCAN_BATCH_MAX_QUERIES) return hipErrorInvalidValue;
     const uint32_t ld4 = ld / 4;
     const f32x4* slab4 = reinterpret_cast<const f32x4*>(slab);
     const uint32_t n32 = (uint32_t)n;
+    const uint32_t groups = (nq + SCAN_BATCH_QB - 1) / SCAN_BATCH_QB;
     int grid = 0;
     hipError_t rc = dispatch_metric(metric, [&](auto M) -> hipError_t {
         constexpr int MM = decltype(M)::value;
@@ -1549,9 +1564,16 @@ hipError_t launch_scan_batch(hipStream_t s, int metric, const float* slab, const
         uint64_t cap = (uint64_t)env_int("VL_BATCH_GRID", 0);                                                 \
         if (cap == 0) cap = (uint64_t)resident;                                                               \
         if (cap > (uint64_t)SCAN_BATCH_MAX_GRID) cap = SCAN_BATCH_MAX_GRID;                                   \
+        if (groups > 1) {                                                                                     \
+            /* several groups in one launch: the resident workgroups are shared out over them, every query's */ \
+            /* lists must fit the finalize kernel without a merge level (<= 64) and the partial-list buffer */  \
+            cap = std::max<uint64_t>(1, cap / groups);                                                        \
+            cap = std::min<uint64_t>(cap, 64);                                                                \
+            cap = std::min<uint64_t>(cap, std::max<uint64_t>(1, PARTIALS32_LISTS / ((uint64_t)groups * SCAN_BATCH_QB))); \
+        }                                                                                                     \
         if (blocks > cap) blocks = cap;                                                                       \
         grid = (int)(blocks < 1 ? 1 : blocks);                                                                \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, slab4, inv_norm, q64, nq, dim, n32, partials);  \
+        hipLaunchKernelGGL(kern, dim3(grid, groups), dim3(256), 0, s, slab4, inv_norm, q64, nq, dim, n32, partials); \
         launched = true;                                                                                      \
     }
         VL_BATCH_SHAPES(VL_TRY_BATCH)

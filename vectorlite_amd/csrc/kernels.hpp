@@ -87,6 +87,7 @@ constexpr int SCAN_MAX_GRID = 4096;
 constexpr int SELECT_MAX_GRID = 1024;
 constexpr int SCAN_BATCH_QB = 8;           // queries served by one slab pass of k_scan_batch
 constexpr int SCAN_BATCH_MAX_GRID = 2048;
+constexpr int SCAN_BATCH_MAX_QUERIES = 512;  // queries one launch_scan_batch call answers: groups of QB as blockIdx.y
 // partial-list buffers: the scan lists (single: SCAN_MAX_GRID; batch: QB x SCAN_BATCH_MAX_GRID),
 // followed by two ping-pong merge regions of QB x 64 lists
 constexpr size_t PARTIALS32_LISTS = (size_t)SCAN_BATCH_QB * SCAN_BATCH_MAX_GRID;
@@ -133,7 +134,9 @@ hipError_t launch_batch_finalize(hipStream_t s, int metric, const Cand32* lists,
                                  SearchResultBlock* out, double in_extra, double* score_scratch,
                                  const ShardRecordSink* sink = nullptr);
 
-// K3: one slab pass for nq <= SCAN_BATCH_QB queries (q64 is [nq, dim]); lists are written query-major.
+// K3: one launch for nq <= SCAN_BATCH_MAX_QUERIES queries (q64 is [nq, dim]) in groups of SCAN_BATCH_QB -- every group is one
+// pass over the slab (blockIdx.y = group); lists are written query-major, plan->grid of them per query (<= 64 when there is
+// more than one group, so that the finalize kernel takes them without a merge level).
 bool scan_batch_supported(uint32_t ld);
 hipError_t launch_scan_batch(hipStream_t s, int metric, const float* slab, const float* inv_norm, const double* q64,
                              uint32_t nq, uint64_t n, uint32_t dim, uint32_t ld, Cand32* partials, ScanPlan* plan);

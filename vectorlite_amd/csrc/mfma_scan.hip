@@ -1374,7 +1374,7 @@ hipError_t launch_rows_bf16_frag(hipStream_t s, const double* master_rows, uint6
 hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf16, const float* row_norm,
                                   const float* row_sqnorm,
                                   const double* q64, uint32_t nq, uint64_t n_rows, uint32_t dim,
-                                  const MfmaScratch& w, Cand32* out_lists)
+                                  const MfmaScratch& w, Cand32* out_lists, MfmaLaunchInfo* info)
 {
     if (nq == 0 || n_rows == 0 || n_rows >= 0xFFFFFFFFull) return hipErrorInvalidValue;
     if (!mfma_scan_supported(dim, metric) || nq > w.nq_cap) return hipErrorInvalidValue;
@@ -1475,6 +1475,15 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
 #undef VL_RLAUNCH
 #undef VL_RLAUNCH2
             if (!r_launched) return hipErrorInvalidValue;
+            if (info) {
+                info->ksteps = (int)(ldb / 16);
+                info->metric = metric;
+                info->chunks = (int)r_chunks;
+                const uint32_t lb = st_end[r_stages - 1], le = st_end[r_stages];
+                info->grid_x = (int)std::max<uint32_t>(1u, std::min<uint32_t>((le - lb + RS_NWAVES - 1) / RS_NWAVES, wg_cap));
+                info->stages = r_stages;
+                info->sample_blocks = (int)sample_blocks;
+            }
             hipLaunchKernelGGL(k_select_candidates, dim3((nq + 3) / 4), dim3(256), 0, s, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, nq, out_lists);
             return hipGetLastError();
         }

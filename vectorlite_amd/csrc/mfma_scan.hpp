@@ -80,10 +80,19 @@ constexpr uint32_t MFMA_TILE_ROWS = 64;
 // slab_bf16: the row-major slab, or the fragment-major one when mfma_rows_kernel(dim).
 // row_norm / row_sqnorm: the arrays launch_rows_bf16 / launch_rows_bf16_frag wrote (dot and Euclidean keys need them).
 // q64: [nq, dim] f64 queries followed by their [nq] f64 norms (0 = answer on the exact path: no candidates are collected).
+// What one launch sequence of the filter looked like (for diagnostics: bench.py ties its PMC traffic figures to it).
+struct MfmaLaunchInfo {
+    int ksteps = 0;        // K steps of 16 = bf16 row stride / 16 (k_mfma_rows<KSTEPS, ...>); 0 = the LDS-tile kernel ran
+    int metric = 0;
+    int chunks = 0;        // query chunks (gridDim.y)
+    int grid_x = 0;        // workgroups per chunk of the LAST pass-1 stage
+    int stages = 0;        // pass-1 launches
+    int sample_blocks = 0; // 32-row blocks the sampling pass covered
+};
 hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf16, const float* row_norm,
                                   const float* row_sqnorm,
                                   const double* q64, uint32_t nq, uint64_t n_rows, uint32_t dim,
-                                  const MfmaScratch& w, Cand32* out_lists);
+                                  const MfmaScratch& w, Cand32* out_lists, MfmaLaunchInfo* info = nullptr);
 
 // Single-query scan of the bf16 slab (opt-in filter): per-workgroup top-64 lists like launch_scan.
 bool scan_bf16_supported(uint32_t dim, int metric);

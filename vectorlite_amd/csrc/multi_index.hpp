@@ -73,6 +73,7 @@ public:
     void profile_enable(bool on);
     void profile_read(uint64_t* n, double* ms, uint64_t* bytes);
     void last_scan(int* variant, int* grid, int* qarg) const { parts_[0]->last_scan(variant, grid, qarg); }
+    void last_filter(int out[6]) const { parts_[0]->last_filter(out); }
     int device() const { return parts_[0]->device(); }  // where device-side inputs are expected
 
     int mode() const { return mode_; }
