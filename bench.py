@@ -355,6 +355,20 @@ def digest64(*arrays) -> int:
     return d
 
 
+def filter_traffic(config: str, workload: dict, plan: dict):
+    """(traffic bytes per batch, traffic / algorithmic) of the batch filter's pass-1 kernel from the committed PMC pass
+    (profiles/traffic.json, rocprofv3 --pmc FETCH_SIZE with the gfx950 corrections) -- only when it was measured on exactly
+    this workload AND this launch plan (vl_index_last_filter): a changed kernel or plan prints null, not stale bytes."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            for e in json.load(f).get("k_mfma_rows", []):
+                if e["config"] == config and e["workload"] == workload and e["plan"] == plan:
+                    return e["traffic_bytes_per_batch"], e["traffic_over_algorithmic"]
+    except Exception:
+        pass
+    return None, None
+
+
 def c3_rows_for(rank: int, world: int, total: int, shards_at_n1: int):
     """Config 3's row range of this rank.  world > 1: the corpus cut into `world` contiguous ranges.  world == 1: the
     FIRST of `shards_at_n1` ranges -- one GPU times one rank's shard of the 8-GPU configuration."""
@@ -423,6 +437,8 @@ def run_c3(V, torch, dist, args, dev, dev_index, rank, world, rehearse, k, cap_s
     dt = (time.perf_counter() - ts) / steps
     shard.profile_enable(False)
     n_pass, filt_ms, _ = shard.profile_read()
+    plan3 = shard.last_filter()
+    traffic3, ratio3 = filter_traffic("c3", {"rows": hi - lo, "dim": dim, "queries": nq, "metric": metric}, plan3)
     prof = comm.profile_read() if comm is not None else None
     if comm is not None:
         comm.profile_enable(False)
@@ -487,7 +503,9 @@ def run_c3(V, torch, dist, args, dev, dev_index, rank, world, rehearse, k, cap_s
                      "filter_kernels_ms_per_batch": round(filt * 1e3, 3),
                      "whole_call": {"achieved": round(flops_rank / dt / 1e12, 1),
                                     "frac": round(flops_rank / dt / 1e12 / MFMA_PEAK_TFLOPS, 4)},
-                     "traffic": None},
+                     "traffic": traffic3, "traffic_over_algorithmic": ratio3,
+                     "algorithmic_bytes_per_batch": rows_rank * (plan3["ksteps"] * 16) * 2 if plan3["ksteps"] else None,
+                     "kernel_plan": plan3},
     }
     if dev_q is not None:
         # the contract's `value` takes its inputs from HBM: the device-query form is the figure, the host form rides beside it
@@ -1170,6 +1188,8 @@ def run_rank(args) -> int:
         w5 = (time.perf_counter() - t5) / reps5
         idx.profile_enable(False)
         n_pass, ms5, _ = idx.profile_read()
+        plan5 = idx.last_filter()
+        traffic5, ratio5 = filter_traffic("c5", {"rows": n, "dim": dim, "queries": nq5, "metric": metric}, plan5)
         kern = ms5 / reps5 * 1e-3
         flops = 2.0 * nq5 * n * dim
         # the contract's `value` takes its inputs from HBM: the same batch resident in device memory
@@ -1202,7 +1222,7 @@ def run_rank(args) -> int:
                                     "frac": round(flops / kern / 1e12 / MFMA_PEAK_TFLOPS, 4) if kern > 0 else None,
                                     "filter_kernels_ms_per_batch": round(kern * 1e3, 3),
                                     "whole_call": {"achieved": round(flops / w5d / 1e12, 1), "frac": round(flops / w5d / 1e12 / MFMA_PEAK_TFLOPS, 4)},
-                                    "traffic": None}}
+                                    "traffic": traffic5, "traffic_over_algorithmic": ratio5, "kernel_plan": plan5}}
 
     def c3_block():
         # config 3's whole corpus as --c3-shards row shards on this card when it fits (10 M x 768: 107 GB with the bf16 copies);

@@ -96,6 +96,9 @@ Workspace::~Workspace()
         if (p) (void)hipFree(p);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    for (hipEvent_t e : mf_ev_done)
+        if (e) (void)hipEventDestroy(e);
+    if (mf_ev_h2d) (void)hipEventDestroy(mf_ev_h2d);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -1366,8 +1369,10 @@ int GpuFlatIndex::ensure_mfma_scratch(Workspace* ws) const
     VL_TRY(pinned_alloc(&ws->mf_h_q64, nqc * (dim_ + 1)));
     VL_TRY(dev_alloc(&ws->mf_lists, nqc * KP));
     VL_TRY(dev_alloc(&ws->mf_scores, nqc * KP));
-    VL_TRY(pinned_alloc(&ws->mf_h_result, nqc));
-    VL_TRY(pinned_alloc(&ws->mf_h_dom, nqc));
+    VL_TRY(pinned_alloc(&ws->mf_h_result, 2 * nqc));  // two launch sequences in flight: one being unpacked, one on the GPU
+    VL_TRY(pinned_alloc(&ws->mf_h_dom, 2 * nqc));
+    for (auto& e : ws->mf_ev_done) VL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    VL_HIP(hipEventCreateWithFlags(&ws->mf_ev_h2d, hipEventDisableTiming));
     ws->mf.nq_cap = (uint32_t)nqc;
     ws->mf.nq_pad_cap = (uint32_t)nqp;
     return OK;
@@ -1395,29 +1400,55 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, const 
         return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count();
     };
     const uint64_t seq = mfma_sequence_queries((uint32_t)dim_);
-    for (uint64_t q0 = 0; q0 < nq; q0 += seq) {
-        const auto t_0 = now();
-        const uint32_t g = (uint32_t)std::min<uint64_t>(seq, nq - q0);
-        std::vector<uint8_t> in_domain(g);
-        if (d_queries) {  // already on this GPU: staged by a kernel; the flags land in pinned memory, read after the sync
+    // Launch sequences run as a two-deep pipeline: sequence s + 1 is staged and enqueued BEFORE the host waits for
+    // sequence s, so the GPU goes from one sequence's finalize straight into the next one's filter while the host
+    // unpacks result blocks (config 5 = two sequences of 2048 queries: rounds 1-3 ran them back to back with a stream
+    // sync, the unpacking and the next staging in between).  Device buffers are shared: stream order keeps one sequence's
+    // kernels behind the previous one's.  What the host touches comes in two copies (result blocks, in-domain flags), and
+    // the one pinned staging area of host queries is reused only after its copies have left (ev_h2d).
+    struct SeqState {
+        uint64_t q0 = 0;
+        uint32_t g = 0;
+        bool live = false;
+        std::vector<uint8_t> in_domain;
+        std::chrono::steady_clock::time_point t0, t1, t2;
+    } sq[2];
+    const bool pipelined = !prof;  // (the profile's event pair brackets one sequence at a time)
+    auto enqueue = [&](int slot, uint64_t q0) -> int {
+        SeqState& S = sq[slot];
+        S.q0 = q0;
+        S.g = (uint32_t)std::min<uint64_t>(seq, nq - q0);
+        S.live = true;
+        S.t0 = now();
+        const uint32_t g = S.g;
+        S.in_domain.assign(g, 0);
+        SearchResultBlock* res = ws->mf_h_result + (size_t)slot * MFMA_MAX_BATCH;
+        unsigned char* dom = ws->mf_h_dom + (size_t)slot * MFMA_MAX_BATCH;
+        if (d_queries) {  // already on this GPU: staged by a kernel; the flags land in pinned memory, read after the wait
             VL_HIP(launch_stage_queries(st, d_queries + q0 * dim_, g, (uint32_t)dim_, DOMAIN_MAX_ABS, DOMAIN_MIN_NORM,
-                                        ws->mf_d_q64, ws->mf_d_q64 + (size_t)g * dim_, ws->mf_h_dom));
+                                        ws->mf_d_q64, ws->mf_d_q64 + (size_t)g * dim_, dom));
         } else {
             // Host queries go to pinned memory (domain test, norm) and over PCIe in pieces: the copy of one piece runs
             // while the host stages the next, so a 6.3 MB batch (1024 x 768) costs about its staging time alone
             // (170 us) instead of staging + copy (170 + 115 us) in front of the first kernel.
+            if (ws->mf_h2d_pending) {  // the previous sequence's copies out of this staging area
+                VL_HIP(hipEventSynchronize(ws->mf_ev_h2d));
+                ws->mf_h2d_pending = false;
+            }
             double* norms = ws->mf_h_q64 + (size_t)g * dim_;
             const uint32_t piece = (uint32_t)std::max<uint64_t>(16, (1u << 20) / (dim_ * sizeof(double)));  // ~1 MB
             for (uint32_t j0 = 0; j0 < g; j0 += piece) {
                 const uint32_t j1 = std::min<uint32_t>(g, j0 + piece);
                 for (uint32_t j = j0; j < j1; ++j)
-                    in_domain[j] = stage_query(queries + (q0 + j) * dim_, ws->mf_h_q64 + (size_t)j * dim_, dim_, &norms[j]) ? 1 : 0;
+                    S.in_domain[j] = stage_query(queries + (q0 + j) * dim_, ws->mf_h_q64 + (size_t)j * dim_, dim_, &norms[j]) ? 1 : 0;
                 VL_HIP(hipMemcpyAsync(ws->mf_d_q64 + (size_t)j0 * dim_, ws->mf_h_q64 + (size_t)j0 * dim_,
                                       (size_t)(j1 - j0) * dim_ * sizeof(double), hipMemcpyHostToDevice, st));
             }
             VL_HIP(hipMemcpyAsync(ws->mf_d_q64 + (size_t)g * dim_, norms, (size_t)g * sizeof(double), hipMemcpyHostToDevice, st));
+            VL_HIP(hipEventRecord(ws->mf_ev_h2d, st));
+            ws->mf_h2d_pending = true;
         }
-        const auto t_1 = now();
+        S.t1 = now();
         if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
         MfmaLaunchInfo li;
         VL_HIP(launch_mfma_candidates(st, metric, slab16, d_norm16_, d_sqnorm_, ws->mf_d_q64, g, n, (uint32_t)dim_,
@@ -1437,16 +1468,26 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, const 
         static const bool split_off = []() { const char* v = getenv("VL_BATCH_FINALIZE"); return v && v[0] == '0'; }();
         if (g >= 8 && !split_off)
             VL_HIP(launch_batch_finalize(st, metric, ws->mf_lists, (int)g, d_master_, ws->mf_d_q64, ws->mf_d_q64 + (size_t)g * dim_,
-                                         (uint32_t)dim_, n, (uint32_t)k_eff, max_row_norm_, ws->mf_h_result, in_extra, ws->mf_scores,
+                                         (uint32_t)dim_, n, (uint32_t)k_eff, max_row_norm_, res, in_extra, ws->mf_scores,
                                          sink ? &seq_sink : nullptr));
         else
             VL_HIP(launch_merge_finalize(st, metric, ws->mf_lists, 1, (int)g, d_master_, ws->mf_d_q64,
                                          ws->mf_d_q64 + (size_t)g * dim_, (uint32_t)dim_, n, (uint32_t)k_eff, max_row_norm_,
-                                         ws->mf_h_result, in_extra, 0, sink ? &seq_sink : nullptr));
-        const auto t_2 = now();
-        VL_HIP(hipStreamSynchronize(st));
+                                         res, in_extra, 0, sink ? &seq_sink : nullptr));
+        VL_HIP(hipEventRecord(ws->mf_ev_done[slot], st));
+        S.t2 = now();
+        return OK;
+    };
+    auto consume = [&](int slot) -> int {
+        SeqState& S = sq[slot];
+        if (!S.live) return OK;
+        S.live = false;
+        const uint32_t g = S.g;
+        const SearchResultBlock* res = ws->mf_h_result + (size_t)slot * MFMA_MAX_BATCH;
+        const unsigned char* dom = ws->mf_h_dom + (size_t)slot * MFMA_MAX_BATCH;
+        VL_HIP(hipEventSynchronize(ws->mf_ev_done[slot]));
         if (d_queries)
-            for (uint32_t j = 0; j < g; ++j) in_domain[j] = ws->mf_h_dom[j];
+            for (uint32_t j = 0; j < g; ++j) S.in_domain[j] = dom[j];
         const auto t_3 = now();
         if (prof) {
             float ms = 0.f;
@@ -1456,24 +1497,10 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, const 
             prof_ms_ += ms;
             prof_bytes_ += n * (uint64_t)mfma_ldb((uint32_t)dim_) * 2;
         }
-        struct TraceOut {
-            bool on;
-            std::chrono::steady_clock::time_point t0, t1, t2, t3;
-            uint32_t g;
-            ~TraceOut()
-            {
-                if (!on) return;
-                const auto t4 = std::chrono::steady_clock::now();
-                auto d = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
-                fprintf(stderr, "[vl batch] %u queries: stage %ld us, enqueue %ld us, wait %ld us, unpack %ld us\n", g, d(t0, t1),
-                        d(t1, t2), d(t2, t3), d(t3, t4));
-            }
-        } trace_out{trace, t_0, t_1, t_2, t_3, g};
-        (void)us;
         for (uint32_t j = 0; j < g; ++j) {
-            const uint64_t qi = q0 + j;
-            const SearchResultBlock& r = ws->mf_h_result[j];
-            if (!in_domain[j] || (r.flags & RESULT_NEEDS_EXACT) || r.n_out != k_eff) continue;
+            const uint64_t qi = S.q0 + j;
+            const SearchResultBlock& r = res[j];
+            if (!S.in_domain[j] || (r.flags & RESULT_NEEDS_EXACT) || r.n_out != k_eff) continue;
             bool ok = true;
             for (uint64_t i = 0; i < k_eff; ++i) ok = ok && r.pos[i] < n;
             if (!ok) {
@@ -1489,8 +1516,27 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, const 
             out_n[qi] = k_eff;
             (*done)[qi] = 1;
         }
+        if (trace) {
+            const auto t4 = now();
+            fprintf(stderr, "[vl batch] %u queries: stage %ld us, enqueue %ld us, wait %ld us, unpack %ld us\n", g, us(S.t0, S.t1),
+                    us(S.t1, S.t2), us(S.t2, t_3), us(t_3, t4));
+        }
+        return OK;
+    };
+    int rc = OK;
+    int slot = 0;
+    for (uint64_t q0 = 0; q0 < nq && rc == OK; q0 += seq, slot ^= 1) {
+        rc = consume(slot);  // the sequence that used this slot's host buffers two steps ago (nothing on the first two turns)
+        if (rc == OK) rc = enqueue(slot, q0);
+        if (rc == OK && !pipelined) rc = consume(slot);
     }
-    return OK;
+    // drain (also on an error: nothing of this call may still be writing result blocks when the workspace goes back)
+    for (int d = 0; d < 2; ++d, slot ^= 1) {
+        const int r2 = rc == OK ? consume(slot) : OK;
+        if (rc == OK) rc = r2;
+    }
+    if (rc != OK) (void)hipStreamSynchronize(st);
+    return rc;
 }
 
 // Queries in device memory.  The MFMA batch path takes them where they are; everything else goes through the host.

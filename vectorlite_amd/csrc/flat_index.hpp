@@ -91,8 +91,11 @@ struct Workspace {
     double* mf_h_q64 = nullptr;             // pinned
     Cand32* mf_lists = nullptr;             // [MFMA_MAX_BATCH, KP]
     double* mf_scores = nullptr;            // [MFMA_MAX_BATCH, KP] reference scores of the candidates (batch finalize scratch)
-    SearchResultBlock* mf_h_result = nullptr;  // pinned [MFMA_MAX_BATCH]
-    unsigned char* mf_h_dom = nullptr;      // pinned [MFMA_MAX_BATCH]: in-domain flags of device-resident queries
+    SearchResultBlock* mf_h_result = nullptr;  // pinned [2][MFMA_MAX_BATCH]: two launch sequences in flight
+    unsigned char* mf_h_dom = nullptr;      // pinned [2][MFMA_MAX_BATCH]: in-domain flags of device-resident queries
+    hipEvent_t mf_ev_done[2] = {nullptr, nullptr};  // behind each sequence's finalize
+    hipEvent_t mf_ev_h2d = nullptr;         // behind the copies out of the pinned query staging area
+    bool mf_h2d_pending = false;
 
     ~Workspace();
 };
