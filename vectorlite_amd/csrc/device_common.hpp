@@ -231,6 +231,29 @@ struct TopList {
     }
 };
 
+// Sort the 64 (key, pos) pairs a wave holds one per lane so that lane i ends with the (63 - i)-th best: the REVERSED order
+// TopList::merge_reversed() takes.  Bitonic network, 21 compare-exchange stages of cross-lane shuffles.
+template <typename K>
+__device__ __forceinline__ void sort64_reversed(K& key, uint32_t& pos)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int k = 2; k <= WAVE; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            const K k2 = __shfl_xor(key, j);
+            const uint32_t p2 = __shfl_xor(pos, j);
+            const bool up = (lane & k) == 0;                 // this block sorts worst-first (k = 64: the whole wave)
+            const bool keep_worse = ((lane & j) == 0) == up; // the lower lane of an ascending pair keeps the worse entry
+            const bool other_worse = better<K>(key, pos, k2, p2);
+            if (keep_worse == other_worse) {
+                key = k2;
+                pos = p2;
+            }
+        }
+    }
+}
+
 // Tree-merge the NW sorted wave lists of a workgroup through LDS; wave 0 ends with the result.
 template <typename K, typename C, int NW>
 __device__ __forceinline__ void block_merge(TopList<K>& L, C* sh /* [NW][64] */)

@@ -273,6 +273,14 @@ __global__ __launch_bounds__(256) void k_scan_batch(const f32x4* __restrict__ sl
     constexpr uint32_t LD4 = G * VPL;
     __shared__ f32x4 qs[QB][LD4];
     __shared__ Cand32 sh[4 * WAVE];
+    // Lazy insertion (round 4).  A row that beats a list's 64th entry is not inserted at once (ballot, rank, two DPP shifts,
+    // selects: ~25 dependent instructions per entry, and on a SMALL index every wave builds its lists from the ~1 500 rows it
+    // sees -- 64 (1 + ln(rows / 64)) ~ 270 insertions per list: 69 % of this kernel on a 50 000-row index, measured with the
+    // insertions compiled out): it is appended to a 64-entry buffer of its (wave, query) in LDS, and a full buffer is sorted
+    // (bitonic, registers) and merged into the list in one go -- ~4 instructions per entry.  The threshold the rows are held
+    // against is a little stale in between (more rows pass than would one by one); nothing that belongs is ever dropped, and
+    // the list after a merge is the top 64 of everything the wave has seen: the same lists as before, bit for bit.
+    __shared__ Cand32 cbuf[4][QB][WAVE];
 
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -297,8 +305,25 @@ __global__ __launch_bounds__(256) void k_scan_batch(const f32x4* __restrict__ sl
     const uint32_t n_waves = gridDim.x * 4;
 
     TopList<float> L[QB];
+    uint32_t n_buf[QB];  // wave-uniform: entries waiting in cbuf[wave][qi]
 #pragma unroll
-    for (int qi = 0; qi < QB; ++qi) L[qi].init();
+    for (int qi = 0; qi < QB; ++qi) {
+        L[qi].init();
+        n_buf[qi] = 0;
+    }
+    auto flush = [&](int qi) {  // cbuf[wave][qi][0 .. n_buf) -> sorted -> merged into L[qi]
+        float fk = -INFINITY;
+        uint32_t fp = POS_SENTINEL;
+        asm volatile("" : "+v"(fk));  // (keeps the -inf out of constant propagation, as in TopList::init)
+        if ((uint32_t)lane < n_buf[qi]) {
+            const Cand32 e = cbuf[wave][qi][lane];
+            fk = e.key;
+            fp = e.pos;
+        }
+        sort64_reversed<float>(fk, fp);
+        L[qi].merge_reversed(fk, fp);
+        n_buf[qi] = 0;
+    };
 
     for (uint32_t s = blockIdx.x * 4 + wave; s < n_steps; s += n_waves) {
         const uint32_t row = s * RPS + g;
@@ -316,7 +341,26 @@ __global__ __launch_bounds__(256) void k_scan_batch(const f32x4* __restrict__ sl
 #pragma unroll
             for (int j = 0; j < VPL; ++j) a = acc4<METRIC>(a, x[j], qs[qi][c + G * j]);
             a = group_reduce<G>(a);
-            L[qi].offer(scan_key<METRIC>(a, inv), row, valid && c == 0 && (uint32_t)qi < n_q);
+#ifndef VL_DBG_K3_NOINSERT
+            {
+                const float key = scan_key<METRIC>(a, inv);
+                const bool cand = valid && c == 0 && (uint32_t)qi < n_q && better<float>(key, row, L[qi].thr_key, L[qi].thr_pos);
+                const unsigned long long m = __ballot(cand);
+                if (m != 0ull) {  // wave-uniform; at most RPS lanes offer a row per step
+                    const uint32_t slot = n_buf[qi] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (cand) {
+                        Cand32 e;
+                        e.key = key;
+                        e.pos = row;
+                        cbuf[wave][qi][slot] = e;
+                    }
+                    n_buf[qi] += (uint32_t)__popcll(m);
+                    if (n_buf[qi] > (uint32_t)(WAVE - RPS)) flush(qi);  // the next step could overflow the buffer
+                }
+            }
+#else  // diagnostic build (tools/build_variant_k.sh): what does the scan cost WITHOUT the top-64 list maintenance?
+            if (scan_key<METRIC>(a, inv) == 12345.678f) L[qi].pos = row;
+#endif
             // one query's LDS reads at a time: without this the scheduler hoists every query's
             // 48 registers of LDS loads above the first FMA and the kernel needs 460+ VGPRs
             __builtin_amdgcn_sched_barrier(0);
@@ -326,6 +370,7 @@ __global__ __launch_bounds__(256) void k_scan_batch(const f32x4* __restrict__ sl
 #pragma unroll
     for (int qi = 0; qi < QB; ++qi) {
         if ((uint32_t)qi < n_q) {  // uniform
+            if (n_buf[qi]) flush(qi);
             block_merge<float, Cand32, 4>(L[qi], sh);
             if (wave == 0) {
                 Cand32 e;
