@@ -18,6 +18,17 @@ def device_asm(tmp_path_factory):
     return out.read_text()
 
 
+@pytest.fixture(scope="module")
+def mfma_asm(tmp_path_factory):
+    """mfma_scan.hip's device assembly, compiled once for the tests below (two minutes of hipcc)."""
+    from vectorlite_amd import build as vbuild
+    out = tmp_path_factory.mktemp("isa_mfma") / "mfma.s"
+    cmd = [vbuild.hipcc(), f"--offload-arch={vbuild.ARCH}"] + vbuild.COMMON + [
+        "--cuda-device-only", "-S", os.path.join(vbuild.CSRC, "mfma_scan.hip"), "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return out.read_text()
+
+
 def test_no_unencodable_64bit_scalar_literal(device_asm):
     # ROCm 7.2 hipcc can emit `s_mov_b64 s[a:b], <64-bit literal>` for gfx950, which the hardware
     # encoding truncates to 32 bits (found on MI355X: a -inf f64 threshold became +0.0).
@@ -54,18 +65,11 @@ def test_scan_kernel_streams_with_16_byte_nontemporal_loads(device_asm):
         assert int(meta.group(1)) <= 128
 
 
-def test_mfma_scan_default_shapes_do_not_spill():
+def test_mfma_scan_default_shapes_do_not_spill(mfma_asm):
     """The batched bf16 MFMA kernels keep 96-192 registers of query fragments per lane; a scheduling
     change once made the sampling pass spill 5000 registers (2.4x slower).  The launch shapes used by
     default (8 waves x 1 tile for dim <= 512, 4 waves x 1 tile for dim 768) must stay spill-free."""
-    from vectorlite_amd import build as vbuild
-    import tempfile
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "mfma.s")
-        cmd = [vbuild.hipcc(), f"--offload-arch={vbuild.ARCH}"] + vbuild.COMMON + [
-            "--cuda-device-only", "-S", os.path.join(vbuild.CSRC, "mfma_scan.hip"), "-o", out]
-        subprocess.run(cmd, check=True, capture_output=True)
-        asm = open(out).read()
+    asm = mfma_asm
     seen = 0
     for block in asm.split("- .agpr_count:")[1:]:
         name = re.search(r"\.name:\s+(\S+)", block).group(1)
@@ -81,3 +85,26 @@ def test_mfma_scan_default_shapes_do_not_spill():
         assert scratch <= 128, (name, scratch)
         assert "v_mfma_f32_16x16x32_bf16" in asm
     assert seen >= 24
+
+
+def test_row_stationary_kernel_shapes_in_the_default_build(mfma_asm):
+    """k_mfma_rows (K4r), the shipped batch filter: the default build holds ONLY the two-waves-per-SIMD shape (RBN 2, NW 8) --
+    the one-wave-per-SIMD shape measured 8-28 % slower in round 4 and compiles in with -DRS_WIDE_SHAPES alone -- and its
+    pass-1 instantiations stay within the spills they are known to have (Euclidean at strides 384 / 512: 10 / 33 registers,
+    there since round 2; everything else none)."""
+    asm = mfma_asm
+    seen = 0
+    for block in asm.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        m = re.search(r"k_mfma_rowsILi(\d+)ELi(\d)ELi(\d)ELi(\d)ELi(\d)E", name)
+        if not m:
+            continue
+        ksteps, mode, metric, rbn, nw = map(int, m.groups())
+        assert (rbn, nw) == (2, 8), name
+        seen += 1
+        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1))
+        vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", block).group(1))
+        assert vgpr <= 256, (name, vgpr)            # two waves per SIMD
+        allowed = 160 if (metric == 1 and ksteps in (24, 32) and mode == 1) else 0
+        assert scratch <= allowed, (name, scratch)
+    assert seen == 30                                # 5 strides x 2 modes x 3 metrics
