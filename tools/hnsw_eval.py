@@ -10,7 +10,7 @@ def main():
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--metric", type=int, default=0)
     ap.add_argument("--nq", type=int, default=1000)
-    ap.add_argument("--efc", type=int, default=128)
+    ap.add_argument("--efc", type=int, default=400)
     ap.add_argument("--efs", default="10,32,64,128")
     ap.add_argument("--latent", type=int, default=0, help="rows = A z + noise with z in R^latent (low intrinsic dimension, like real embeddings); 0 = i.i.d. gaussian")
     a = ap.parse_args()
