@@ -1114,3 +1114,28 @@ def test_mfma_batches_whose_chunk_count_8_does_not_divide(V, O, dim, metric, nq)
     ref = O.FlatOracle(dim, ids, rows)
     for qi in (0, nq // 2, nq - 1):
         assert_same(V, (bi[qi], bs[qi]), ref.search(Q[qi], 10, M[metric]), (dim, metric, nq, qi))
+
+
+@pytest.mark.parametrize("dim", [32, 64, 50, 96])
+def test_f32_batch_path_many_groups_per_launch_matches_the_oracle(V, O, dim):
+    """Round 4's K3: up to 512 queries per scan launch (groups of 8 as blockIdx.y), one finalize launch, lazy list insertion,
+    four lanes per row at strides 32 / 64.  Small indexes (below the MFMA filter's 8192 rows) and Manhattan take this path:
+    batches that straddle the group (8) and launch (512) boundaries against the oracle, all four metrics, ties included."""
+    rng = np.random.default_rng(1000 + dim)
+    for n in (70, 3000):
+        rows = rng.standard_normal((n, dim))
+        rows[n // 2] = rows[3]                      # an exact duplicate: insertion order decides
+        ids = permuted_ids(n)
+        gpu = V.FlatIndex(dim)
+        gpu.add_rows(ids, rows, validate=False)
+        ref = O.FlatOracle(dim, ids, rows)
+        Q = rng.standard_normal((1030, dim))
+        Q[5] = rows[3]
+        Q[600] = rows[3]
+        for metric in range(4):
+            for nq in (7, 9, 513, 1030):
+                bi, bs, bn = gpu.search_batch(Q[:nq], 10, metric)
+                assert bn.tolist() == [10] * nq
+                for qi in sorted({0, 5, 6, 7, 8, nq - 1, min(511, nq - 1), min(512, nq - 1), min(600, nq - 1)}):
+                    ri, rs = ref.search(Q[qi], 10, metric)
+                    assert bi[qi].tolist() == ri.tolist() and bs[qi].tolist() == rs.tolist(), (n, metric, nq, qi)

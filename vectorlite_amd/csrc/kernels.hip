@@ -1574,8 +1574,11 @@ hipError_t launch_scan(hipStream_t s, int metric, const float* slab, const float
 }
 
 // Batch shapes: one (G, VPL) per supported row length, QB = 8 queries per pass.
-// (lanes per row, 16-byte chunks per lane): row strides 32, 64, 96, 128, 192, 256, 320, 384, 512, 640, 768, 1024, 1536 floats
-#define VL_BATCH_SHAPES(X) X(8, 1) X(8, 2) X(8, 3) X(8, 4) X(8, 6) X(8, 8) X(8, 10) X(8, 12) X(8, 16) X(16, 10) X(16, 12) X(16, 16) X(16, 24)
+// (lanes per row, 16-byte chunks per lane): row strides 32, 64, 96, 128, 192, 256, 320, 384, 512, 640, 768, 1024, 1536 floats.
+// The first shape whose G * VPL matches the stride runs.  Strides 32 and 64 take FOUR lanes per row (16 rows per wave step):
+// at such lengths a (row, query) pair is ~35 instructions of which 19 are the cross-lane reduction, the key compare, the
+// ballot and the branch -- per ROW costs that 16 rows per step halve (round 4, `tools/manhattan_probe.py`).
+#define VL_BATCH_SHAPES(X) X(4, 2) X(4, 4) X(8, 1) X(8, 2) X(8, 3) X(8, 4) X(8, 6) X(8, 8) X(8, 10) X(8, 12) X(8, 16) X(16, 10) X(16, 12) X(16, 16) X(16, 24)
 
 bool scan_batch_supported(uint32_t ld)
 {
