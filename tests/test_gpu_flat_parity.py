@@ -1136,6 +1136,6 @@ def test_f32_batch_path_many_groups_per_launch_matches_the_oracle(V, O, dim):
             for nq in (7, 9, 513, 1030):
                 bi, bs, bn = gpu.search_batch(Q[:nq], 10, metric)
                 assert bn.tolist() == [10] * nq
-                for qi in sorted({0, 5, 6, 7, 8, nq - 1, min(511, nq - 1), min(512, nq - 1), min(600, nq - 1)}):
+                for qi in sorted({min(q, nq - 1) for q in (0, 5, 6, 7, 8, 511, 512, 600, nq - 1)}):
                     ri, rs = ref.search(Q[qi], 10, metric)
                     assert bi[qi].tolist() == ri.tolist() and bs[qi].tolist() == rs.tolist(), (n, metric, nq, qi)
