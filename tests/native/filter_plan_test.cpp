@@ -1,5 +1,5 @@
 // CPU check of csrc/filter_plan.hpp: the launch plan of the MFMA batch filter over a sweep of index sizes, chunk counts and
-// knob settings.  Invariants: the sample is a prefix of the blocks and holds min(n, 65536) rows at least; the sampling grid
+// knob settings.  Invariants: the sample is a prefix of the blocks and holds min(n, 32768) rows at least; the sampling grid
 // reports at most MFMA_GROUPS groups, every group owns a block, and never fewer than 128 groups (or one per block) --
 // with 64 the threshold would be the smallest group maximum; the stages tile [0, n_blocks) in order; and the defaults
 // are the measured ones (1 stage on short scans, 2 on shards of ~1 M rows, 4 from 4 M rows on).
@@ -33,7 +33,7 @@ int main()
                     const uint32_t nb = (uint32_t)((n + 31) / 32);
                     CHECK(p.n_blocks == nb);
                     CHECK(p.sample_blocks >= 1 && p.sample_blocks <= nb);
-                    const uint64_t floor_rows = smin ? smin : 65536u;
+                    const uint64_t floor_rows = smin ? smin : 32768u;
                     CHECK((uint64_t)p.sample_blocks * 32 >= (n < floor_rows ? (n / 32) * 32 : floor_rows));
                     CHECK(p.groups == p.gx0 * p.gpw && p.groups <= MAXG && p.gpw >= 1 && p.gpw <= NW);
                     CHECK(p.groups <= p.sample_blocks || p.gpw == NW);          // a group per block at most, or per wave
@@ -56,7 +56,7 @@ int main()
     {
         uint64_t n = 1250000; uint32_t cap = 23; vl::FilterKnobs kn;
         const vl::FilterPlan p = vl::filter_plan(n, cap, NW, MAXG, kn);   // config 3's shard: 11 chunks of 96 queries
-        CHECK(p.stages == 2 && p.st_end[1] == 39063u * 2 / 16 && p.sample_blocks == 2048 && p.groups == 184);
+        CHECK(p.stages == 2 && p.st_end[1] == 39063u * 2 / 16 && p.sample_blocks == 39063u / 32 && p.groups == 184);
     }
     std::printf("filter_plan: %ld plans checked\n", plans);
     return 0;

@@ -36,7 +36,11 @@ inline FilterPlan filter_plan(uint64_t n_rows, uint32_t wg_cap, uint32_t n_waves
     // the sample: 1/32 of the blocks; 1/64 on long scans (>= 4 M rows), where the floor of 65536 rows is far away and the
     // looser thresholds only add a few hundred candidates per query to the first stage
     const uint32_t div = kn.sample_div ? kn.sample_div : (n_blocks >= 131072u ? 64u : 32u);
-    const uint32_t min_rows = kn.sample_min_rows >= 2048u ? kn.sample_min_rows : 65536u;
+    // floor of the sample: 32768 rows (round 4; 65536 before).  Config 3's shard, one process, knob combinations interleaved
+    // (tools/c3_knob_sweep.py, profiles/r04_c3_knob_sweep.jsonl): 1.624 ms per batch against 1.659 with 65536 -- the sampling
+    // pass costs what a pass-1 scan of the same rows costs and collects nothing, and the looser thresholds only add ~100
+    // candidates per query to the first stage; 16384 is slower again (1.639), as are three stages or a first stage of 1/16 or 3/16.
+    const uint32_t min_rows = kn.sample_min_rows >= 2048u ? kn.sample_min_rows : 32768u;
     p.sample_blocks = std::max<uint32_t>(n_blocks / div, std::min<uint32_t>(n_blocks, min_rows / 32u));
     // sampling launch: the grid of pass 1 (every CU busy, one round), each workgroup reporting gpw groups so that
     // k_thresholds sees up to max_groups of them

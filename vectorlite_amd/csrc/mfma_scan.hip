@@ -10,7 +10,7 @@
 //     queries per wave held in registers.
 //
 // bf16 scores are only a CANDIDATE FILTER.  The Q x N score matrix is never written:
-//   pass 0 (a sample: 1/32 .. 1/64 of the rows, at least 65536 of them): every group of row blocks reports, per query,
+//   pass 0 (a sample: 1/32 .. 1/64 of the rows, at least 32768 of them): every group of row blocks reports, per query,
 //     its best key; the 64th largest of those maxima is a valid lower bound T_q of the query's 64th best key
 //     (64 distinct rows reach it);
 //   pass 1 (all rows, in up to four stages of growing size; between stages T_q is raised to the 64th best
