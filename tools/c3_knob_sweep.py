@@ -31,7 +31,7 @@ def main():
     Q /= np.linalg.norm(Q, axis=1, keepdims=True)
     dQ = torch.from_numpy(Q).to(dev)
     knobs = ("VL_MFMA_SAMPLE_MIN", "VL_MFMA_STAGES", "VL_MFMA_STAGE1")
-    combos = [(None, None, None)] + [c for c in itertools.product(("16384", "32768", None), ("2", "3"), ("1", "2", "3")) if c != (None, "2", "2")]
+    combos = [(None, None, None)] + [c for c in itertools.product(("16384", "65536", None), ("2", "3"), ("1", "2", "3")) if c != (None, "2", "2")]
 
     def apply(c):
         for k, v in zip(knobs, c):
@@ -58,7 +58,7 @@ def main():
     apply(combos[0])
     out = []
     for c in combos:
-        out.append({"sample_min": c[0] or "default(65536)", "stages": c[1] or "default(2)", "stage1_16ths": c[2] or "default(2)",
+        out.append({"sample_min": c[0] or "default(32768)", "stages": c[1] or "default(2)", "stage1_16ths": c[2] or "default(2)",
                     "filter_ms_median": round(float(np.median(t[c])), 4), "filter_ms_min": round(float(np.min(t[c])), 4), "answers_identical": same[c]})
     out.sort(key=lambda e: e["filter_ms_median"])
     for e in out:
