@@ -824,10 +824,10 @@ int GpuFlatIndex::search_batch_locked(const double* queries, uint64_t nq, uint64
         {   // ONE scan launch (groups of 8 queries as blockIdx.y: each group is one pass over the slab) and ONE finalize launch
             ScanPlan plan;
             VL_HIP(launch_scan_batch(st, metric, d_slab_, d_inv_norm_, ws->k3_d_q64, cnt, n, (uint32_t)dim_, ld_, ws->d_partials, &plan));
+            if (prof) VL_HIP(hipEventRecord(ws->ev1, st));
             VL_HIP(launch_merge_finalize(st, metric, ws->d_partials, plan.grid, (int)cnt, d_master_, ws->k3_d_q64, d_norms,
                                          (uint32_t)dim_, n, (uint32_t)k_eff, max_row_norm_, ws->k3_h_result));
         }
-        if (prof) VL_HIP(hipEventRecord(ws->ev1, st));
         VL_HIP(hipStreamSynchronize(st));
         if (prof) {  // (the events bracket the one scan launch: `passes` slab passes side by side)
             float ms = 0.f;
