@@ -1424,9 +1424,15 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, const 
         S.in_domain.assign(g, 0);
         SearchResultBlock* res = ws->mf_h_result + (size_t)slot * MFMA_MAX_BATCH;
         unsigned char* dom = ws->mf_h_dom + (size_t)slot * MFMA_MAX_BATCH;
+        bool prepared = false;
         if (d_queries) {  // already on this GPU: staged by a kernel; the flags land in pinned memory, read after the wait
-            VL_HIP(launch_stage_queries(st, d_queries + q0 * dim_, g, (uint32_t)dim_, DOMAIN_MAX_ABS, DOMAIN_MIN_NORM,
-                                        ws->mf_d_q64, ws->mf_d_q64 + (size_t)g * dim_, dom));
+            hipError_t pe = hipSuccess;
+            prepared = frag && launch_prepare_queries(st, d_queries + q0 * dim_, g, (uint32_t)dim_, DOMAIN_MAX_ABS, DOMAIN_MIN_NORM,
+                                                      ws->mf_d_q64, ws->mf_d_q64 + (size_t)g * dim_, dom, ws->mf, &pe);
+            VL_HIP(pe);
+            if (!prepared)
+                VL_HIP(launch_stage_queries(st, d_queries + q0 * dim_, g, (uint32_t)dim_, DOMAIN_MAX_ABS, DOMAIN_MIN_NORM,
+                                            ws->mf_d_q64, ws->mf_d_q64 + (size_t)g * dim_, dom));
         } else {
             // Host queries go to pinned memory (domain test, norm) and over PCIe in pieces: the copy of one piece runs
             // while the host stages the next, so a 6.3 MB batch (1024 x 768) costs about its staging time alone
@@ -1452,7 +1458,7 @@ int GpuFlatIndex::search_batch_mfma(Workspace* ws, const double* queries, const 
         if (prof) VL_HIP(hipEventRecord(ws->ev0, st));
         MfmaLaunchInfo li;
         VL_HIP(launch_mfma_candidates(st, metric, slab16, d_norm16_, d_sqnorm_, ws->mf_d_q64, g, n, (uint32_t)dim_,
-                                      ws->mf, ws->mf_lists, &li));
+                                      ws->mf, ws->mf_lists, &li, prepared));
         {
             const int v[6] = {li.ksteps, li.metric, li.chunks, li.grid_x, li.stages, li.sample_blocks};
             for (int i = 0; i < 6; ++i) last_filter_[i].store(v[i], std::memory_order_relaxed);

@@ -57,6 +57,13 @@ uint32_t mfma_sequence_queries(uint32_t dim);
 hipError_t launch_stage_queries(hipStream_t s, const double* d_src, uint32_t nq, uint32_t dim, double max_abs,
                                 double min_norm, double* d_dst, double* d_norms, unsigned char* in_domain);
 
+// launch_stage_queries, the bf16 conversion of the staged queries and the clearing of the candidate counters as ONE kernel,
+// for a sequence the row-stationary kernel will answer.  Returns false (nothing launched) when that kernel does not apply --
+// the caller then stages with launch_stage_queries and launch_mfma_candidates converts as before; true: pass
+// queries_prepared = true to launch_mfma_candidates.  *err carries the launch status.
+bool launch_prepare_queries(hipStream_t s, const double* d_src, uint32_t nq, uint32_t dim, double max_abs, double min_norm,
+                            double* d_dst, double* d_norms, unsigned char* in_domain, const MfmaScratch& w, hipError_t* err);
+
 // f64 master rows [n, dim] -> UNIT-NORMALISED bf16 rows [n, ldb] (x/|x| in f64 -> f32 -> bf16, round to
 // nearest even), |row| and |row|^2 (f64, rounded once to f32)
 hipError_t launch_rows_bf16(hipStream_t s, const double* master, uint64_t n, uint32_t dim, void* out_bf16,
@@ -92,7 +99,8 @@ struct MfmaLaunchInfo {
 hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf16, const float* row_norm,
                                   const float* row_sqnorm,
                                   const double* q64, uint32_t nq, uint64_t n_rows, uint32_t dim,
-                                  const MfmaScratch& w, Cand32* out_lists, MfmaLaunchInfo* info = nullptr);
+                                  const MfmaScratch& w, Cand32* out_lists, MfmaLaunchInfo* info = nullptr,
+                                  bool queries_prepared = false);
 
 // Single-query scan of the bf16 slab (opt-in filter): per-workgroup top-64 lists like launch_scan.
 bool scan_bf16_supported(uint32_t dim, int metric);
