@@ -369,6 +369,20 @@ def filter_traffic(config: str, workload: dict, plan: dict):
     return None, None
 
 
+def hnsw_traffic(workload: dict, evals_per_query: float):
+    """FETCH_SIZE bytes per batch of the HNSW walk kernel from the committed PMC pass (profiles/traffic.json), attached only when it
+    was measured on exactly this workload and the walks did the same work (distance evaluations per query within 0.5 %: the
+    graph build is deterministic, so they normally agree to the digit)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            for e in json.load(f).get("k_hnsw_search", []):
+                if e["workload"] == workload and abs(e["distance_evals_per_query"] - evals_per_query) <= 0.005 * evals_per_query:
+                    return e["traffic_bytes_per_batch"], e["traffic_over_algorithmic"]
+    except Exception:
+        pass
+    return None, None
+
+
 def c3_rows_for(rank: int, world: int, total: int, shards_at_n1: int):
     """Config 3's row range of this rank.  world > 1: the corpus cut into `world` contiguous ranges.  world == 1: the
     FIRST of `shards_at_n1` ranges -- one GPU times one rank's shard of the 8-GPU configuration."""
@@ -684,10 +698,12 @@ def run_c4(V, torch, args, dev, dev_index, k, cap_s, log_fn):
             recq = float(np.mean([sum(1 for x in hi_[i, :int(hnn[i])] if D[i][int(x)] <= kth[i]) / float(k) for i in range(nchk)]))
             row_bytes = (evq - max(ef, k)) * dim * 4 + max(ef, k) * dim * 8
             gbps = (nq / dtq) * row_bytes / 1e9
+            tr4, ratio4 = hnsw_traffic({"data": name, "rows": n, "dim": dim, "queries": nq, "ef": ef, "ef_construction": efc_default}, evq)
             per_ef[f"ef{ef}"] = {"recall_at_10_vs_exact_f64_order": round(rec, 4), "recall_at_10_vs_u64_distance_order": round(recq, 4),
                                 "queries_per_s": round(nq / dtq, 1), "distance_evals_per_query": round(evq, 1),
                                 "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": round(gbps, 1),
-                                             "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+                                             "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": tr4, "traffic_over_algorithmic": ratio4,
+                                             "algorithmic_bytes_per_batch": int(nq * row_bytes),
                                              "note": "random 1.5-3 KB row reads of a latency-bound walk: rows read x row bytes / time"},
                                 "beam": "strict reference rule ef = min(k, len)" if strict else f"ef = {ef}"}
         # a lone query at the reference's strict beam
