@@ -188,6 +188,45 @@ def test_config3_shard_shape_through_vl_shard_search_batch():
         comm.close()
 
 
+@pytest.mark.parametrize("metric", [0, 1, 3])
+def test_device_written_exchange_record_over_several_launch_sequences_and_with_patched_queries(metric):
+    """The finalize kernel writes this rank's exchange record in device memory (ShardRecordSink): a batch longer than one
+    launch sequence (2500 queries at d = 128: 2048 + 452), with queries whose cut falls inside a block of 70 identical rows
+    (the bf16 filter cannot certify those: they are re-answered exactly and patched into the record).  The answer
+    must equal the plain batch search row for row, and the record must have been written on the device."""
+    import vectorlite_amd as V
+    from vectorlite_amd.sharded import Comm, ShardedFlatIndex
+    rng = np.random.default_rng(100 + metric)
+    n, dim, nq, k = 20_000, 128, 2500, 10
+    rows = rng.standard_normal((n, dim))
+    twin = rng.standard_normal(dim)
+    where = rng.choice(n, 70, replace=False)
+    rows[where] = twin
+    ids = np.arange(n, dtype=np.uint64) * np.uint64(3) + np.uint64(11)
+    shard = V.FlatIndex(dim, device=0)
+    shard.add_rows(ids, rows, validate=False)
+    Q = rng.standard_normal((nq, dim))
+    planted = [0, 7, 2047, 2048, 2049, 2499]          # both sides of the sequence boundary, first and last query
+    Q[planted] = twin + 1e-3 * rng.standard_normal((len(planted), dim))
+    comm = Comm(Comm.unique_id(), 1, 0, 0)
+    try:
+        sh = ShardedFlatIndex(shard, comm=comm)
+        before = comm.record_paths()
+        i, s, cnt, p = sh.search_batch(Q, k, metric, with_positions=True)
+        after = comm.record_paths()
+        assert (after["on_device"] - before["on_device"], after["via_host"] - before["via_host"]) == (1, 0)
+        bp, bi, bs, bn = shard.search_batch_positions(Q, k, metric)
+        assert cnt.tolist() == bn.tolist() == [k] * nq
+        assert i.tolist() == bi.tolist() and s.tolist() == bs.tolist() and p.tolist() == bp.tolist()
+        for qi in planted + [1, 1000, 2046]:
+            si, ss = shard.search_arrays(Q[qi], k, metric)
+            assert si.tolist() == i[qi].tolist() and ss.tolist() == s[qi].tolist()
+        for qi in planted:                              # ties inside the block: insertion order decides
+            assert p[qi].tolist() == np.sort(where)[:k].tolist() and len(set(s[qi].tolist())) == 1
+    finally:
+        comm.close()
+
+
 def test_a_nan_score_on_one_shard_is_the_whole_calls_panic():
     """FlatIndex::search panics on a NaN score (partial_cmp().unwrap(), src/index/flat.rs:116) -> VL_ERR_NAN_SCORE; in the
     sharded form the failing shard's status travels inside the exchange and every rank reports it."""
