@@ -1272,35 +1272,49 @@ def run_rank(args) -> int:
         # the first shared pass of a handle builds the batch filter's bf16 copy of the rows (once; ~30 ms at 10 M x 384):
         # outside the timed loop, like every other warm-up of this file
         idx.search_batch(Qt[:16], k, metric)
-        b0, q0 = idx.coalesce_stats()
-        res = [None] * (T * per)
-        lat = [0.0] * (T * per)
-        bar = threading.Barrier(T + 1)
+        def closed_loop():
+            b0, q0 = idx.coalesce_stats()
+            w0, us0 = idx.coalesce_gather()
+            res = [None] * (T * per)
+            lat = [0.0] * (T * per)
+            bar = threading.Barrier(T + 1)
 
-        def worker(t):
+            def worker(t):
+                bar.wait()
+                for i in range(t * per, (t + 1) * per):
+                    ta = time.perf_counter()
+                    res[i] = idx.search_arrays(Qt[i], k, metric)
+                    lat[i] = time.perf_counter() - ta
+            th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+            for x in th:
+                x.start()
             bar.wait()
-            for i in range(t * per, (t + 1) * per):
-                ta = time.perf_counter()
-                res[i] = idx.search_arrays(Qt[i], k, metric)
-                lat[i] = time.perf_counter() - ta
-        th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
-        for x in th:
-            x.start()
-        bar.wait()
-        tc = time.perf_counter()
-        for x in th:
-            x.join()
-        el = time.perf_counter() - tc
-        b1, q1 = idx.coalesce_stats()
-        same = sum(int(res[t * per][0].tolist() == lone[t][0].tolist() and res[t * per][1].tolist() == lone[t][1].tolist()) for t in range(T))
-        la = np.sort(np.asarray(lat)) * 1e3
+            tc = time.perf_counter()
+            for x in th:
+                x.join()
+            el = time.perf_counter() - tc
+            b1, q1 = idx.coalesce_stats()
+            w1, us1 = idx.coalesce_gather()
+            same = sum(int(res[t * per][0].tolist() == lone[t][0].tolist() and res[t * per][1].tolist() == lone[t][1].tolist()) for t in range(T))
+            la = np.sort(np.asarray(lat)) * 1e3
+            return {"value": round(T * per / el, 1), "unit": "queries/s",
+                    "latency_ms": {"mean": round(float(la.mean()), 3), "p50": round(float(la[len(la) // 2]), 3), "p99": round(float(la[int(len(la) * 0.99)]), 3)},
+                    "identical_to_lone_search": f"{same}/{T}",
+                    "passes": int(b1 - b0), "queries_per_pass": round((q1 - q0) / max(b1 - b0, 1), 2),
+                    "leader_waits": int(w1 - w0), "leader_wait_ms_total": round((us1 - us0) / 1e3, 2)}
+
+        closed_loop()                      # settle: thread start-up, the coalescer's pass history
+        r_on = closed_loop()
+        idx.coalesce_gather(False)
+        r_off = closed_loop()
+        idx.coalesce_gather(True)
         out["concurrent_16_threads"] = {
-            "threads": T, "queries": T * per, "value": round(T * per / el, 1), "unit": "queries/s",
-            "latency_ms": {"mean": round(float(la.mean()), 3), "p50": round(float(la[len(la) // 2]), 3), "p99": round(float(la[int(len(la) * 0.99)]), 3)},
-            "identical_to_lone_search": f"{same}/{T}",
-            "passes": int(b1 - b0), "queries_per_pass": round((q1 - q0) / max(b1 - b0, 1), 2),
-            "handle": "as created: coalescing on by default (max 256 per pass, window 0); lone callers are the timed region above",
-            "note": "concurrent callers share slab passes (bf16 MFMA filter + exact f64 finalize): every answer is the lone search's"}
+            "threads": T, "queries": T * per, **r_on,
+            "handle": "as created: coalescing on by default (max 256 per pass, window 0, adaptive gather); lone callers are the timed region above",
+            "without_adaptive_gather": r_off,
+            "note": "concurrent callers share slab passes (bf16 MFMA filter + exact f64 finalize): every answer is the lone search's; "
+                    "the gather lets a leader wait (<= a quarter of the recent pass time) for as many callers as the last passes held, "
+                    "instead of leading a pass of one while the other 15 are on their way back"}
 
     def c4_block():
         other["c4_hnsw"] = run_c4(V, torch, args, dev, dev_index, k, args.block_cap_s * 2.5, log)  # three builds at ef_construction 400 + the sweep

@@ -397,9 +397,17 @@ int vl_index_set_single_filter(vl_index *h, int mode);
  * path (no wait, no batch kernels).  The first pass that answers two or more queries on an index of >= 8192 rows
  * builds the batch filter's bf16 copy of the rows (+2 bytes per value).  VL_COALESCE=0 in the
  * environment makes handles created afterwards start with it off; vl_index_set_coalescing(h, 0, 0) turns it off.
- * vl_index_coalesce_stats: passes run and queries answered by them since creation. */
+ * vl_index_coalesce_stats: passes run and queries answered by them since creation.
+ * ADAPTIVE GATHER (window 0 only; on by default, VL_COALESCE_ADAPTIVE=0 or vl_index_coalesce_gather(h, 0, ..) turns it
+ * off): N callers in a closed loop otherwise fall into passes of 1 and N - 1 in turn (the first caller back leads at
+ * once, alone).  Every pass leaves an estimate of the callers in the loop (requests answered + compatible requests queued
+ * behind it); a leader that finds fewer queued than the larger of the last two estimates waits for them, at most a quarter
+ * of the recent pass time and never more than 400 us; a lone caller (estimates 1, 1) never waits.
+ * vl_index_coalesce_gather: adaptive = 1 / 0 sets the switch, -1 leaves it; waits / waited_us (may be NULL) report the
+ * passes whose leader waited and the microseconds spent waiting since creation. */
 int vl_index_set_coalescing(vl_index *h, int max_batch, int window_us);
 int vl_index_coalesce_stats(const vl_index *h, uint64_t *batches, uint64_t *queries);
+int vl_index_coalesce_gather(vl_index *h, int adaptive, uint64_t *waits, uint64_t *waited_us);
 
 /* HNSW handle: queries walked and Metric::distance evaluations (src/index/hnsw.rs:113-174) made for them since
  * creation: navigation evaluations on the f32 rows (dim x 4 bytes each) plus one exact f64 evaluation per entry of

@@ -81,6 +81,8 @@ def test_bench_child_process_prints_the_whole_contract_line(steps, warmup):
     cc = out["concurrent_16_threads"]
     assert cc["threads"] == 16 and cc["identical_to_lone_search"] == "16/16" and cc["value"] > 0
     assert cc["passes"] <= cc["queries"] and cc["latency_ms"]["p99"] >= cc["latency_ms"]["p50"] > 0
+    off = cc["without_adaptive_gather"]        # the same loop with the leader's gather off: window 0 as rounds 1-3 ran it
+    assert off["identical_to_lone_search"] == "16/16" and off["leader_waits"] == 0 and off["value"] > 0
     c4 = oc["c4_hnsw"]
     assert c4["parity"].startswith("unpinned") and set(c4["data"]) == {"latent16", "clustered", "iid_gaussian"}
     for dist_name in ("latent16", "clustered"):   # the construction beam's sweep: 128 (rounds 1-3), 200, 400 (the default)

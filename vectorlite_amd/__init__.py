@@ -472,6 +472,12 @@ class FlatIndex:
         _raise(self._L.vl_index_coalesce_stats(self._h, C.byref(b), C.byref(q)))
         return int(b.value), int(q.value)
 
+    def coalesce_gather(self, adaptive: Optional[bool] = None) -> Tuple[int, int]:
+        """Switch the coalescer's adaptive gather (None leaves it) and read (passes whose leader waited, microseconds waited)."""
+        w, us = C.c_uint64(0), C.c_uint64(0)
+        _raise(self._L.vl_index_coalesce_gather(self._h, -1 if adaptive is None else int(bool(adaptive)), C.byref(w), C.byref(us)))
+        return int(w.value), int(us.value)
+
     def last_scan(self) -> Dict[str, int]:
         """Which k_scan instantiation / grid answered the last single search (vl_index_last_scan)."""
         v, g, q = C.c_int(0), C.c_int(0), C.c_int(0)
@@ -571,6 +577,12 @@ class HNSWIndex:
         b, q = C.c_uint64(0), C.c_uint64(0)
         _raise(self._L.vl_index_coalesce_stats(self._h, C.byref(b), C.byref(q)))
         return int(b.value), int(q.value)
+
+    def coalesce_gather(self, adaptive: Optional[bool] = None) -> Tuple[int, int]:
+        """Switch the coalescer's adaptive gather (None leaves it) and read (passes whose leader waited, microseconds waited)."""
+        w, us = C.c_uint64(0), C.c_uint64(0)
+        _raise(self._L.vl_index_coalesce_gather(self._h, -1 if adaptive is None else int(bool(adaptive)), C.byref(w), C.byref(us)))
+        return int(w.value), int(us.value)
 
     def graph(self, with_rows: bool = False) -> Dict[str, Any]:
         """The graph as it stands (vl_index_hnsw_graph_info / _export): entry, max_level, m, m0 and the arrays

@@ -20,7 +20,7 @@ SYMBOLS = [
     "vl_index_len", "vl_index_is_empty", "vl_index_dimension", "vl_index_get_vector", "vl_index_max_id",
     "vl_index_export", "vl_index_search_positions", "vl_index_search_batch_positions", "vl_index_search_batch_dev", "vl_index_search_batch_embeddings_f32", "vl_index_hnsw_distances", "vl_hnsw_score",
     "vl_last_error", "vl_last_dim_mismatch", "vl_last_path", "vl_index_force_path", "vl_index_set_single_filter",
-    "vl_index_set_coalescing", "vl_index_coalesce_stats", "vl_index_hnsw_walk_stats",
+    "vl_index_set_coalescing", "vl_index_coalesce_stats", "vl_index_coalesce_gather", "vl_index_hnsw_walk_stats",
     "vl_vlc_open", "vl_vlc_close", "vl_vlc_name", "vl_vlc_info", "vl_vlc_side_table", "vl_vlc_read_values", "vl_vlc_build_index",
     "vl_index_profile_enable", "vl_index_profile_read", "vl_index_last_scan", "vl_index_last_filter", "vl_runtime_info",
     "vl_comm_unique_id", "vl_comm_create", "vl_comm_destroy", "vl_comm_world", "vl_comm_rank", "vl_comm_profile_enable", "vl_comm_profile_read", "vl_comm_record_paths",
@@ -103,6 +103,7 @@ def load() -> C.CDLL:
     sig("vl_vlc_build_index", i32, [vp, i32, C.POINTER(vp)])
     sig("vl_index_set_coalescing", i32, [vp, i32, i32])
     sig("vl_index_coalesce_stats", i32, [vp, p_u64, p_u64])
+    sig("vl_index_coalesce_gather", i32, [vp, i32, p_u64, p_u64])
     sig("vl_index_hnsw_walk_stats", i32, [vp, p_u64, p_u64])
     sig("vl_index_hnsw_set_min_beam", i32, [vp, C.c_uint32])
     p_u32 = C.POINTER(C.c_uint32)

@@ -792,6 +792,14 @@ int vl_index_coalesce_stats(const vl_index* h, uint64_t* batches, uint64_t* quer
     return VL_OK;
 }
 
+int vl_index_coalesce_gather(vl_index* h, int adaptive, uint64_t* waits, uint64_t* waited_us)
+{
+    if (!h || adaptive < -1 || adaptive > 1) return VL_ERR_INVALID_ARG;
+    if (h->hnsw) h->hnsw->coalesce_gather(adaptive, waits, waited_us);
+    else on_flat(h, [&](auto* f) { f->coalesce_gather(adaptive, waits, waited_us); return (int)VL_OK; });
+    return VL_OK;
+}
+
 int vl_index_hnsw_graph_info(const vl_index* h, uint64_t* n_nodes, uint32_t* entry, int* max_level, uint32_t* m,
                              uint32_t* m0, uint64_t* upper_slots)
 {

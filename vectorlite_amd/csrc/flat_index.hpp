@@ -197,6 +197,13 @@ public:
     // (COALESCE_DEFAULT_BATCH, 0) unless VL_COALESCE=0.
     void set_coalescing(int max_batch, int window_us) { co_.configure(max_batch, window_us, (int)MFMA_MAX_BATCH); }
     void coalesce_stats(uint64_t* batches, uint64_t* queries) const { co_.stats(batches, queries); }
+    // adaptive: 1 / 0 switch the leader's adaptive gather (coalescer.hpp) on / off, -1 leaves it; waits, waited_us: passes whose
+    // leader waited for its peers and the time spent waiting, since creation
+    void coalesce_gather(int adaptive, uint64_t* waits, uint64_t* waited_us) const
+    {
+        if (adaptive >= 0) co_.set_adaptive(adaptive != 0);
+        co_.gather_stats(waits, waited_us);
+    }
     void profile_enable(bool on);
     void profile_read(uint64_t* n, double* ms, uint64_t* bytes);
     // which k_scan instantiation (G * 10000 + VPL * 100 + U; negative: the generic kernel's G), on how many workgroups,

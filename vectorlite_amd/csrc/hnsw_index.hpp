@@ -66,6 +66,11 @@ public:
     // concurrent single-query search() calls share walk launches (coalescer.hpp); 0 / 1 = off; on by default (create())
     void set_coalescing(int max_batch, int window_us) { co_.configure(max_batch, window_us, 4096); }
     void coalesce_stats(uint64_t* batches, uint64_t* queries) const { co_.stats(batches, queries); }
+    void coalesce_gather(int adaptive, uint64_t* waits, uint64_t* waited_us) const
+    {
+        if (adaptive >= 0) co_.set_adaptive(adaptive != 0);
+        co_.gather_stats(waits, waited_us);
+    }
 
     static int create(uint64_t dim, int metric, const HnswParams& p, int device, HnswIndex** out);
     ~HnswIndex();

@@ -711,6 +711,18 @@ void MultiFlatIndex::coalesce_stats(uint64_t* batches, uint64_t* queries) const
     if (batches) *batches = b;
     if (queries) *queries = q;
 }
+void MultiFlatIndex::coalesce_gather(int adaptive, uint64_t* waits, uint64_t* waited_us) const
+{
+    uint64_t w = 0, us = 0;
+    for (auto& x : parts_) {
+        uint64_t ww = 0, uu = 0;
+        x->coalesce_gather(adaptive, &ww, &uu);
+        w += ww;
+        us += uu;
+    }
+    if (waits) *waits = w;
+    if (waited_us) *waited_us = us;
+}
 void MultiFlatIndex::profile_enable(bool on)
 {
     for (auto& x : parts_) x->profile_enable(on);

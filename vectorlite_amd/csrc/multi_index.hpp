@@ -70,6 +70,7 @@ public:
     void set_single_filter(int mode);
     void set_coalescing(int max_batch, int window_us);
     void coalesce_stats(uint64_t* batches, uint64_t* queries) const;
+    void coalesce_gather(int adaptive, uint64_t* waits, uint64_t* waited_us) const;
     void profile_enable(bool on);
     void profile_read(uint64_t* n, double* ms, uint64_t* bytes);
     void last_scan(int* variant, int* grid, int* qarg) const { parts_[0]->last_scan(variant, grid, qarg); }
