@@ -1050,16 +1050,67 @@ __global__ __launch_bounds__(256) void k_thresholds(const int* __restrict__ gmax
     if (lane == 0) thr[q] = (q_norms[q] == 0.0) ? INFINITY : t;
 }
 
+// Composite of a candidate: order-preserving key bits, then ~position -- unsigned order = (key desc, position asc) rank.
+__device__ __forceinline__ unsigned long long cand_composite(const Cand32 e)
+{
+    return ((unsigned long long)((uint32_t)enc_f(e.key) ^ 0x80000000u) << 32) | (unsigned long long)(0xFFFFFFFFu - e.pos);
+}
+
+// Top-64 of the 64 * VALS composites a wave holds (0 = padding, below every real composite: a real one has ~pos >= 1 in
+// its low word): a bit-by-bit search finds the 64th largest, the <= 64 entries at or above it are compacted through
+// `row` (64 LDS slots of this wave) and ranked by counting -- no insertion loop.  Writes the sorted list, sentinels behind.
+template <int VALS>
+__device__ __forceinline__ void top64_of_composites(const unsigned long long (&c)[VALS], unsigned long long* row, int lane,
+                                                    Cand32* __restrict__ out)
+{
+    unsigned long long t = 0ull;  // the 64th largest composite (0 when there are fewer than 64)
+    for (int b = 63; b >= 0; --b) {
+        const unsigned long long tc = t | (1ull << b);
+        uint32_t n_ge = 0;
+#pragma unroll
+        for (int i = 0; i < VALS; ++i) n_ge += (uint32_t)__popcll(__ballot(c[i] >= tc));
+        if (n_ge >= 64u) t = tc;  // wave-uniform
+    }
+    __builtin_amdgcn_wave_barrier();  // `row` may still be read as the wave's candidate buffer by a slower lane
+    uint32_t base = 0;
+#pragma unroll
+    for (int i = 0; i < VALS; ++i) {
+        const bool sel = c[i] != 0ull && c[i] >= t;
+        const unsigned long long mk = __ballot(sel);
+        const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+        if (sel && slot < 64u) row[slot] = c[i];
+        base += (uint32_t)__popcll(mk);
+    }
+    const uint32_t kept = base < 64u ? base : 64u;  // composites are distinct (positions are), so base <= 64
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long me = (uint32_t)lane < kept ? row[lane] : 0ull;
+    uint32_t rank = 0;
+    for (int jx = 0; jx < 64; ++jx) rank += read_lane(me, jx) > me ? 1u : 0u;
+    Cand32 res;
+    res.key = -INFINITY;
+    res.pos = POS_SENTINEL;
+    if ((uint32_t)lane < kept) {
+        res.key = dec_f((int)((uint32_t)(me >> 32) ^ 0x80000000u));
+        res.pos = 0xFFFFFFFFu - (uint32_t)me;
+        out[rank] = res;
+    } else {
+        out[lane] = res;  // sentinels behind the real entries
+    }
+}
+
 // Per query: top-64 of its candidate buffer by (key desc, position asc) -> one sorted list.  One wave per query.
-// Up to 1024 candidates (the usual few hundred) sit in registers as 64-bit composites (order-preserving key bits,
-// then ~position): a bit-by-bit search finds the 64th largest composite, the <= 64 entries at or above it are
-// compacted through LDS and ranked by counting -- no insertion loop over the whole buffer.  Longer buffers (up to the
-// cap) take the sorted-list path.
+// The buffer holds every row that beat the threshold of ITS stage; what can still be in the top 64 at the end is what
+// beats the FINAL threshold thr[q] (a valid lower bound of the 64th best key: at least 64 rows reach it and all rows have
+// been through pass 1), i.e. the 64 that set it plus the last stage's finds -- one or two hundred of the one to four
+// thousand in the buffer.  So: stream the buffer once (8 loads per lane in flight), compact the composites at or above
+// thr[q] into LDS (<= 512), and select among those with 1..8 values per lane.  Buffers whose filtered set is out of
+// that range (or thr == nullptr) take the old paths: every candidate in registers (<= 1024), or the sorted-list walk.
+constexpr int SEL_KEEP = 512;
 __global__ __launch_bounds__(256) void k_select_candidates(const Cand32* __restrict__ cand,
                                                            const uint32_t* __restrict__ cnt, uint32_t cap, uint32_t nq,
-                                                           Cand32* __restrict__ lists)
+                                                           const float* __restrict__ thr, Cand32* __restrict__ lists)
 {
-    __shared__ unsigned long long sh[4][64];
+    __shared__ unsigned long long sh[4][SEL_KEEP];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t q = blockIdx.x * 4 + wave;
@@ -1074,47 +1125,55 @@ __global__ __launch_bounds__(256) void k_select_candidates(const Cand32* __restr
         out[lane] = res;
         return;
     }
+    if (thr != nullptr && n > 128u) {
+        const float t = thr[q];
+        uint32_t m = 0;
+        for (uint32_t i0 = 0; i0 < n; i0 += 512u) {
+            Cand32 e[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t jx = i0 + (uint32_t)(lane + 64 * u);
+                e[u] = mine[jx < n ? jx : n - 1u];  // clamped, never predicated: the loads go out together
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t jx = i0 + (uint32_t)(lane + 64 * u);
+                const bool sel = jx < n && e[u].key >= t;
+                const unsigned long long mk = __ballot(sel);
+                const uint32_t slot = m + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                if (sel && slot < (uint32_t)SEL_KEEP) sh[wave][slot] = cand_composite(e[u]);
+                m += (uint32_t)__popcll(mk);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (m >= 64u && m <= (uint32_t)SEL_KEEP) {  // wave-uniform
+#define VL_SEL_FROM_LDS(VALS)                                                                                 \
+    {                                                                                                         \
+        unsigned long long c[VALS];                                                                           \
+        _Pragma("unroll") for (int i = 0; i < VALS; ++i)                                                      \
+        {                                                                                                     \
+            const uint32_t jx = (uint32_t)(lane + 64 * i);                                                    \
+            c[i] = jx < m ? sh[wave][jx] : 0ull;                                                              \
+        }                                                                                                     \
+        top64_of_composites<VALS>(c, sh[wave], lane, out);                                                    \
+    }
+            if (m <= 128u) VL_SEL_FROM_LDS(2)
+            else if (m <= 256u) VL_SEL_FROM_LDS(4)
+            else VL_SEL_FROM_LDS(8)
+#undef VL_SEL_FROM_LDS
+            return;
+        }
+    }
     if (n <= 1024u) {
         constexpr int VALS = 16;
         unsigned long long c[VALS];
 #pragma unroll
         for (int i = 0; i < VALS; ++i) {
             const uint32_t jx = (uint32_t)(lane + 64 * i);
-            c[i] = 0ull;  // below every real composite (a real one has ~pos >= 1 in its low word: pos < 0xFFFFFFFF)
-            if (jx < n) {
-                const Cand32 e = mine[jx];
-                c[i] = ((unsigned long long)((uint32_t)enc_f(e.key) ^ 0x80000000u) << 32) | (unsigned long long)(0xFFFFFFFFu - e.pos);
-            }
+            c[i] = 0ull;
+            if (jx < n) c[i] = cand_composite(mine[jx]);
         }
-        unsigned long long t = 0ull;  // the 64th largest composite (0 when there are fewer than 64)
-        for (int b = 63; b >= 0; --b) {
-            const unsigned long long tc = t | (1ull << b);
-            uint32_t n_ge = 0;
-#pragma unroll
-            for (int i = 0; i < VALS; ++i) n_ge += (uint32_t)__popcll(__ballot(c[i] >= tc));
-            if (n_ge >= 64u) t = tc;  // wave-uniform
-        }
-        uint32_t base = 0;
-#pragma unroll
-        for (int i = 0; i < VALS; ++i) {
-            const bool sel = c[i] != 0ull && c[i] >= t;
-            const unsigned long long mk = __ballot(sel);
-            const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-            if (sel && slot < 64u) sh[wave][slot] = c[i];
-            base += (uint32_t)__popcll(mk);
-        }
-        const uint32_t kept = base < 64u ? base : 64u;  // composites are distinct (positions are), so base <= 64
-        __builtin_amdgcn_wave_barrier();
-        const unsigned long long me = (uint32_t)lane < kept ? sh[wave][lane] : 0ull;
-        uint32_t rank = 0;
-        for (int jx = 0; jx < 64; ++jx) rank += read_lane(me, jx) > me ? 1u : 0u;
-        if ((uint32_t)lane < kept) {
-            res.key = dec_f((int)((uint32_t)(me >> 32) ^ 0x80000000u));
-            res.pos = 0xFFFFFFFFu - (uint32_t)me;
-            out[rank] = res;
-        } else {
-            out[lane] = res;  // sentinels behind the real entries
-        }
+        top64_of_composites<VALS>(c, sh[wave], lane, out);
         return;
     }
     TopList<float> L;
@@ -1136,26 +1195,78 @@ __global__ __launch_bounds__(256) void k_select_candidates(const Cand32* __restr
 // Those are 64 distinct rows, so the value is still a lower bound of the query's 64th best key, and it
 // is much tighter than the sampling bound: the later stages (most of the rows) take the candidate branch
 // of k_mfma_scan's epilogue a few times less often.  One wave per query.
+// A buffer of more than 512 (the second and third refinement of a 10 M-row pass: one to four thousand) is streamed once,
+// 8 loads per lane in flight, and only the keys at or above the CURRENT T_q are kept (compacted into LDS): keys below it
+// cannot raise it -- if fewer than 64 candidates reach T_q the 64th largest is below T_q and T_q stays -- and those at
+// or above it are the 64 that set it plus the finds since, a few hundred.  (The sorted-list walk this replaces took
+// 27-100 us per launch: one dependent load per 64 candidates.)
+constexpr int REF_KEEP = 1024;
 __global__ __launch_bounds__(256) void k_refine_thresholds(const Cand32* __restrict__ cand, const uint32_t* __restrict__ cnt,
                                                           uint32_t cap, uint32_t nq, float* __restrict__ thr)
 {
+    __shared__ float keep[4][REF_KEEP];
     const int lane = threadIdx.x & 63;
-    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave = threadIdx.x >> 6;
+    const uint32_t q = blockIdx.x * 4 + wave;
     if (q >= nq) return;
     const uint32_t n = cnt[q];
     if (n < 64u || n > cap) return;  // too few to say anything / overflowed (the host redoes that query)
-    if (n <= 512u) {  // the usual case between stages: every candidate key in registers, one selection
+    const Cand32* mine = cand + (size_t)q * cap;
+    if (n <= 512u) {  // the usual case after the first stage: every candidate key in registers, one selection
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const uint32_t j = (uint32_t)(lane + 64 * i);
-            v[i] = j < n ? cand[(size_t)q * cap + j].key : -INFINITY;
+            v[i] = j < n ? mine[j].key : -INFINITY;
         }
         const float t64 = kth64_of_wave<8>(v);
         if (lane == 0 && t64 > thr[q]) thr[q] = t64;
         return;
     }
-    TopList<float> L;
+    const float t_old = thr[q];
+    uint32_t m = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += 512u) {
+        float kv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t jx = i0 + (uint32_t)(lane + 64 * u);
+            kv[u] = mine[jx < n ? jx : n - 1u].key;  // clamped, never predicated: the loads go out together
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t jx = i0 + (uint32_t)(lane + 64 * u);
+            const bool sel = jx < n && kv[u] >= t_old;
+            const unsigned long long mk = __ballot(sel);
+            const uint32_t slot = m + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            if (sel && slot < (uint32_t)REF_KEEP) keep[wave][slot] = kv[u];
+            m += (uint32_t)__popcll(mk);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (m < 64u) return;  // the 64th largest candidate is below T_q: T_q stays (wave-uniform)
+    if (m <= (uint32_t)REF_KEEP) {
+        float t64;
+        if (m <= 512u) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t j = (uint32_t)(lane + 64 * i);
+                v[i] = j < m ? keep[wave][j] : -INFINITY;
+            }
+            t64 = kth64_of_wave<8>(v);
+        } else {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t j = (uint32_t)(lane + 64 * i);
+                v[i] = j < m ? keep[wave][j] : -INFINITY;
+            }
+            t64 = kth64_of_wave<16>(v);
+        }
+        if (lane == 0 && t64 > t_old) thr[q] = t64;
+        return;
+    }
+    TopList<float> L;  // more than REF_KEEP candidates at or above T_q (a first refinement after a loose sampling bound)
     L.init();
     for (uint32_t i0 = 0; i0 < n; i0 += 64) {
         const uint32_t i = i0 + lane;
@@ -1163,7 +1274,7 @@ __global__ __launch_bounds__(256) void k_refine_thresholds(const Cand32* __restr
         Cand32 e;
         e.key = 0.f;
         e.pos = 0;
-        if (ok) e = cand[(size_t)q * cap + i];
+        if (ok) e = mine[i];
         L.offer(e.key, e.pos, ok);
     }
     const float t64 = read_lane(L.key, 63);
@@ -1543,7 +1654,8 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
                 info->stages = r_stages;
                 info->sample_blocks = (int)sample_blocks;
             }
-            hipLaunchKernelGGL(k_select_candidates, dim3((nq + 3) / 4), dim3(256), 0, s, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, nq, out_lists);
+            hipLaunchKernelGGL(k_select_candidates, dim3((nq + 3) / 4), dim3(256), 0, s, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, nq,
+                               (const float*)w.thr, out_lists);
             return hipGetLastError();
         }
     }
@@ -1639,7 +1751,8 @@ hipError_t launch_mfma_candidates(hipStream_t s, int metric, const void* slab_bf
 #undef VL_LAUNCH2
 #undef VL_LAUNCH3
     if (!launched) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_select_candidates, dim3((nq + 3) / 4), dim3(256), 0, s, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, nq, out_lists);
+    hipLaunchKernelGGL(k_select_candidates, dim3((nq + 3) / 4), dim3(256), 0, s, w.cand, w.cnt, (uint32_t)MFMA_CAND_CAP, nq,
+                               (const float*)w.thr, out_lists);
     return hipGetLastError();
 }
 
