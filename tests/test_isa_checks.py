@@ -96,15 +96,16 @@ def test_row_stationary_kernel_shapes_in_the_default_build(mfma_asm):
     seen = 0
     for block in asm.split("- .agpr_count:")[1:]:
         name = re.search(r"\.name:\s+(\S+)", block).group(1)
-        m = re.search(r"k_mfma_rowsILi(\d+)ELi(\d)ELi(\d)ELi(\d)ELi(\d)E", name)
+        m = re.search(r"k_mfma_rowsILi(\d+)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb([01])E", name)
         if not m:
             continue
-        ksteps, mode, metric, rbn, nw = map(int, m.groups())
+        ksteps, mode, metric, rbn, nw, stream = map(int, m.groups())
         assert (rbn, nw) == (2, 8), name
+        assert not (stream and mode == 0), name     # nontemporal row loads: single-chunk launches of pass 1 only
         seen += 1
         scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1))
         vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", block).group(1))
         assert vgpr <= 256, (name, vgpr)            # two waves per SIMD
         allowed = 160 if (metric == 1 and ksteps in (24, 32) and mode == 1) else 0
         assert scratch <= allowed, (name, scratch)
-    assert seen == 30                                # 5 strides x 2 modes x 3 metrics
+    assert seen == 45                                # 5 strides x 3 metrics x (sampling, pass 1, pass 1 with streaming loads)
