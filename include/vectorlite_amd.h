@@ -392,7 +392,7 @@ int vl_index_set_single_filter(vl_index *h, int mode);
  * exactly the result and status a lone vl_index_search returns.  window_us > 0 additionally lets a
  * lone caller wait that long for company.  max_batch 0/1 = off.
  * DEFAULT (round 4): ON with max_batch 256 and window 0 for every handle -- the reference's many-readers usage
- * (16 threads on one 10 M x 384 index: 456 QPS / 35 ms per query with separate scans, 5.3 k QPS / 3.0 ms coalesced,
+ * (16 threads on one 10 M x 384 index: 456 QPS / 35 ms per query with separate scans, 9.8 k QPS / 1.6 ms coalesced,
  * identical answers); a lone caller finds no pass in flight, leads a pass of one and runs exactly the single-search
  * path (no wait, no batch kernels).  The first pass that answers two or more queries on an index of >= 8192 rows
  * builds the batch filter's bf16 copy of the rows (+2 bytes per value).  VL_COALESCE=0 in the
