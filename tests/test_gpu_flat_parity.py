@@ -674,6 +674,43 @@ def test_large_index_properties(V):
     assert r2[0].id == r[1].id and r2[0].score == r[1].score
 
 
+@pytest.mark.parametrize("copies", [700, 3000])
+def test_staged_filter_with_thousands_of_equal_keys_in_a_candidate_buffer(V, copies):
+    """The staged bf16 filter on an index long enough for refinements between stages (600 k x 64, 2048 queries: 16 query
+    chunks), with `copies` identical rows spread over the index and queries next to them: their keys are EQUAL, so they all
+    sit at or above every threshold -- the candidate buffers of those queries hold hundreds to thousands of entries that no
+    refinement can thin out (k_refine_thresholds' and k_select_candidates' long-buffer paths, beyond what their LDS
+    compaction keeps).  Every row of the batch must equal the lone search, whose ties resolve in insertion order."""
+    import torch
+    n, dim, nq, k = 600_000, 64, 2048, 10
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(11)
+    x = torch.randn((n, dim), dtype=torch.float64, device="cuda:0", generator=g)
+    x /= torch.linalg.vector_norm(x, dim=1, keepdim=True)
+    rng = np.random.default_rng(5)
+    where = np.sort(rng.choice(n, copies, replace=False))
+    twin = rng.standard_normal(dim)
+    twin /= np.linalg.norm(twin)
+    x[torch.from_numpy(where).to("cuda:0")] = torch.from_numpy(twin).to("cuda:0")
+    idx = V.FlatIndex(dim)
+    idx.add_rows(np.arange(n, dtype=np.uint64) + 5, x, validate=False)
+    del x
+    Q = unit_rows(rng, nq, dim)
+    planted = [0, 95, 96, 1023, 1024, 2047]
+    for qi in planted:
+        v = twin + 0.02 * rng.standard_normal(dim)
+        Q[qi] = v / np.linalg.norm(v)
+    for metric in (0, 1, 3):
+        bi, bs, bn = idx.search_batch(Q, k, metric)
+        assert idx.last_filter()["stages"] >= 2          # refinements ran
+        assert bn.tolist() == [k] * nq
+        for qi in planted + [1, 500, 1500]:
+            si, ss = idx.search_arrays(Q[qi], k, metric)
+            assert bi[qi].tolist() == si.tolist() and bs[qi].tolist() == ss.tolist(), (metric, qi)
+        for qi in planted:                               # the twins win, first inserted first
+            assert bi[qi].tolist() == (where[:k] + 5).tolist() and len(set(bs[qi].tolist())) == 1, (metric, qi)
+
+
 # ---------------------------------------------------------------------------------------------
 # adversarial near-ties: the f32 / bf16 filters cannot order these rows, the bound check must notice
 # ---------------------------------------------------------------------------------------------
