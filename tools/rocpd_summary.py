@@ -29,10 +29,11 @@ def demangle(name: str) -> str:
 
 def itanium_fallback(name: str) -> str:
     """c++filt does not know the bf16 type code (DF16b): render `11k_mfma_rowsILi24ELi1ELi0EE...` as k_mfma_rows<24, 1, 0>."""
-    m = re.search(r"\d+(k_\w+?)I((?:Li\d+E)+)E", name)
+    m = re.search(r"\d+(k_\w+?)I((?:L[ib]\d+E)+)E", name)
     if not m:
         return name
-    return "vl::" + m.group(1) + "<" + ", ".join(re.findall(r"Li(\d+)E", m.group(2))) + ">("
+    args = [v if t == "i" else ("true" if v == "1" else "false") for t, v in re.findall(r"L([ib])(\d+)E", m.group(2))]
+    return "vl::" + m.group(1) + "<" + ", ".join(args) + ">("
 
 
 def short(name: str) -> str:

@@ -1103,19 +1103,42 @@ __device__ __forceinline__ void top64_of_composites(const unsigned long long (&c
     }
 }
 
+// The 64th largest 32-bit key (high word of a composite) among the 64 * VALS composites a wave holds; 0 when fewer than 64
+// are real.  32 rounds of VALS one-instruction compares -- half the rounds and a third of the work of the 64-bit search.
+template <int VALS>
+__device__ __forceinline__ uint32_t kth64_key_of_composites(const unsigned long long (&c)[VALS])
+{
+    uint32_t hi[VALS];  // a real entry's key word is never 0 (that would be the encoding of a NaN): padding (0) is never counted
+#pragma unroll
+    for (int i = 0; i < VALS; ++i) hi[i] = (uint32_t)(c[i] >> 32);
+    uint32_t t = 0;
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t tc = t | (1u << b);
+        uint32_t n_ge = 0;
+#pragma unroll
+        for (int i = 0; i < VALS; ++i) n_ge += (uint32_t)__popcll(__ballot(hi[i] >= tc));
+        if (n_ge >= 64u) t = tc;  // wave-uniform
+    }
+    return t;
+}
+
 // Per query: top-64 of its candidate buffer by (key desc, position asc) -> one sorted list.  One wave per query.
 // The buffer holds every row that beat the threshold of ITS stage; what can still be in the top 64 at the end is what
 // beats the FINAL threshold thr[q] (a valid lower bound of the 64th best key: at least 64 rows reach it and all rows have
-// been through pass 1), i.e. the 64 that set it plus the last stage's finds -- one or two hundred of the one to four
-// thousand in the buffer.  So: stream the buffer once (8 loads per lane in flight), compact the composites at or above
-// thr[q] into LDS (<= 512), and select among those with 1..8 values per lane.  Buffers whose filtered set is out of
-// that range (or thr == nullptr) take the old paths: every candidate in registers (<= 1024), or the sorted-list walk.
-constexpr int SEL_KEEP = 512;
+// been through pass 1), i.e. the 64 that set it plus the last stage's finds -- a few hundred of the one to four thousand
+// in the buffer.  So: (A) stream the buffer once (8 loads per lane in flight) and compact the composites at or above
+// thr[q] into LDS (<= 1024); (B) find the 64th largest KEY among them (32-bit search) and compact again what reaches it:
+// the top 64 plus whatever ties the 64th key, normally under 128; (C) rank those by the full composite (2 values per lane).
+// Fallbacks: no usable filter -> every candidate goes through (B) (n <= 1024); more than 128 tie the 64th key -> the
+// full-composite search over the first set; a buffer that fits neither -> the sorted-list walk.
+constexpr int SEL_KEEP = 1024;
+constexpr int SEL_TIES = 128;
 __global__ __launch_bounds__(256) void k_select_candidates(const Cand32* __restrict__ cand,
                                                            const uint32_t* __restrict__ cnt, uint32_t cap, uint32_t nq,
                                                            const float* __restrict__ thr, Cand32* __restrict__ lists)
 {
     __shared__ unsigned long long sh[4][SEL_KEEP];
+    __shared__ unsigned long long sh2[4][SEL_TIES];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t q = blockIdx.x * 4 + wave;
@@ -1130,15 +1153,15 @@ __global__ __launch_bounds__(256) void k_select_candidates(const Cand32* __restr
         out[lane] = res;
         return;
     }
-    if (thr != nullptr && n > 128u) {
-        const float t = thr[q];
+    // (A) composites at or above t -> sh[wave]; m = how many there are (stored: the first SEL_KEEP)
+    auto gather = [&](float t) {
         uint32_t m = 0;
         for (uint32_t i0 = 0; i0 < n; i0 += 512u) {
             Cand32 e[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const uint32_t jx = i0 + (uint32_t)(lane + 64 * u);
-                e[u] = mine[jx < n ? jx : n - 1u];  // clamped, never predicated: the loads go out together
+                e[u] = mine[jx < n ? jx : (n ? n - 1u : 0u)];  // clamped, never predicated: the loads go out together
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -1151,34 +1174,56 @@ __global__ __launch_bounds__(256) void k_select_candidates(const Cand32* __restr
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (m >= 64u && m <= (uint32_t)SEL_KEEP) {  // wave-uniform
-#define VL_SEL_FROM_LDS(VALS)                                                                                 \
-    {                                                                                                         \
-        unsigned long long c[VALS];                                                                           \
-        _Pragma("unroll") for (int i = 0; i < VALS; ++i)                                                      \
-        {                                                                                                     \
-            const uint32_t jx = (uint32_t)(lane + 64 * i);                                                    \
-            c[i] = jx < m ? sh[wave][jx] : 0ull;                                                              \
-        }                                                                                                     \
-        top64_of_composites<VALS>(c, sh[wave], lane, out);                                                    \
+        return m;
+    };
+    uint32_t m = 0;
+    bool have = false;
+    if (n == 0) {
+        out[lane] = res;
+        return;
     }
-            if (m <= 128u) VL_SEL_FROM_LDS(2)
-            else if (m <= 256u) VL_SEL_FROM_LDS(4)
-            else VL_SEL_FROM_LDS(8)
+    if (thr != nullptr && n > 128u) {
+        m = gather(thr[q]);
+        have = m >= 64u && m <= (uint32_t)SEL_KEEP;  // wave-uniform
+    }
+    if (!have && n <= (uint32_t)SEL_KEEP) {
+        m = gather(-INFINITY);  // keys are finite: everything
+        have = true;
+    }
+    if (have) {
+#define VL_SEL_FROM_LDS(VALS)                                                                                              \
+    {                                                                                                                      \
+        unsigned long long c[VALS];                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < VALS; ++i)                                                                   \
+        {                                                                                                                  \
+            const uint32_t jx = (uint32_t)(lane + 64 * i);                                                                 \
+            c[i] = jx < m ? sh[wave][jx] : 0ull;                                                                           \
+        }                                                                                                                  \
+        const uint32_t t64 = kth64_key_of_composites<VALS>(c); /* 0: fewer than 64 entries, all of them stay */            \
+        uint32_t m2 = 0;                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < VALS; ++i)                                                                   \
+        {                                                                                                                  \
+            const bool sel = c[i] != 0ull && (uint32_t)(c[i] >> 32) >= t64;                                                \
+            const unsigned long long mk = __ballot(sel);                                                                   \
+            const uint32_t slot = m2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u)); \
+            if (sel && slot < (uint32_t)SEL_TIES) sh2[wave][slot] = c[i];                                                  \
+            m2 += (uint32_t)__popcll(mk);                                                                                  \
+        }                                                                                                                  \
+        __builtin_amdgcn_wave_barrier();                                                                                   \
+        if (m2 <= (uint32_t)SEL_TIES) { /* wave-uniform */                                                                 \
+            unsigned long long d[2];                                                                                       \
+            d[0] = (uint32_t)lane < m2 ? sh2[wave][lane] : 0ull;                                                           \
+            d[1] = (uint32_t)lane + 64u < m2 ? sh2[wave][lane + 64] : 0ull;                                                \
+            top64_of_composites<2>(d, sh[wave], lane, out);                                                                \
+        } else {                                                                                                           \
+            top64_of_composites<VALS>(c, sh[wave], lane, out);                                                             \
+        }                                                                                                                  \
+    }
+        if (m <= 128u) VL_SEL_FROM_LDS(2)
+        else if (m <= 256u) VL_SEL_FROM_LDS(4)
+        else if (m <= 512u) VL_SEL_FROM_LDS(8)
+        else VL_SEL_FROM_LDS(16)
 #undef VL_SEL_FROM_LDS
-            return;
-        }
-    }
-    if (n <= 1024u) {
-        constexpr int VALS = 16;
-        unsigned long long c[VALS];
-#pragma unroll
-        for (int i = 0; i < VALS; ++i) {
-            const uint32_t jx = (uint32_t)(lane + 64 * i);
-            c[i] = 0ull;
-            if (jx < n) c[i] = cand_composite(mine[jx]);
-        }
-        top64_of_composites<VALS>(c, sh[wave], lane, out);
         return;
     }
     TopList<float> L;
