@@ -46,6 +46,7 @@ extern "C" {
     fn vl_index_len(h: *const vl_index) -> u64;
     fn vl_index_get_vector(h: *const vl_index, id: u64, out: *mut f64) -> c_int;
     fn vl_index_export(h: *const vl_index, out_ids: *mut u64, out_values: *mut f64) -> c_int;
+    #[allow(dead_code)]
     fn vl_index_set_coalescing(h: *mut vl_index, max_batch: c_int, window_us: c_int) -> c_int;
     fn vl_index_search_batch(h: *const vl_index, queries: *const f64, nq: u64, q_len: u64, k: u64, metric: c_int, out_ids: *mut u64, out_scores: *mut f64, out_n: *mut u64) -> c_int;
     fn vl_index_search_ef(h: *const vl_index, queries: *const f64, nq: u64, q_len: u64, k: u64, ef: u32, metric: c_int, out_ids: *mut u64, out_scores: *mut f64, out_n: *mut u64) -> c_int;
@@ -204,8 +205,8 @@ impl GpuFlatIndex {
             side.entry(v.id).or_insert((v.text, v.metadata)); // first row of an id wins, like get_vector's find()
         }
         // tokio workers search concurrently under RwLock::read and share slab passes: the library does that by default
-        // (window 0); a server that prefers throughput over a lone caller's latency adds a 200 us window here
-        unsafe { vl_index_set_coalescing(raw, 64, 200) };
+        // (up to 256 queries per pass, window 0, and a leader waits briefly for peers still on their way back from the
+        // previous pass -- vl_index_coalesce_gather); vl_index_set_coalescing(raw, 0, 0) would turn it off
         GpuFlatIndex(Handle { raw, dim, side })
     }
 }
@@ -243,7 +244,7 @@ impl GpuFlatIndex {
         for v in data {
             side.entry(v.id).or_insert((v.text, v.metadata));
         }
-        unsafe { vl_index_set_coalescing(raw, 64, 200) }; // one queue per replica
+        // coalescing is on by default, one queue per replica
         GpuFlatIndex(Handle { raw, dim, side })
     }
 }
