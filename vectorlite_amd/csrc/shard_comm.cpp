@@ -441,6 +441,15 @@ int ShardComm::search_batch(const GpuFlatIndex* shard, const double* queries, ui
     // failure) build the record on the host as before.
     bool on_device = false;
     {
+        // the 4 header words of a device-written record ("ok", this shard's length, the dimension) are known now: they
+        // travel to d_send while the search runs, not after it (a record built on the host overwrites them below)
+        unsigned long long* hdr = merger_.h_hdr();
+        hdr[0] = OK;
+        hdr[1] = lens_[(size_t)rank_];
+        hdr[2] = dim_;
+        hdr[3] = 0;
+        SH_HIP_OR_ABORT(hipSetDevice(merger_.device()));
+        SH_HIP_OR_ABORT(hipMemcpyAsync(merger_.d_send(), hdr, SHARD_HDR_WORDS * 8, hipMemcpyHostToDevice, merger_.stream()));
         int drc = OK;
         try {
             drc = shard->search_batch_to_record(queries, queries_on_device, nq, q_len, ks, metric, offset_, merger_.d_send(), &on_device);
@@ -453,11 +462,6 @@ int ShardComm::search_batch(const GpuFlatIndex* shard, const double* queries, ui
     }
     std::string local_msg;
     if (on_device) {
-        unsigned long long* hdr = merger_.h_hdr();
-        hdr[0] = OK;
-        hdr[1] = lens_[(size_t)rank_];
-        hdr[2] = dim_;
-        hdr[3] = 0;
         ++rec_device_;
     } else {
         shard_search_local(shard, offset_, lens_[(size_t)rank_], total_ != 0, queries, nq, q_len, ks, metric, merger_.h_send(),
@@ -468,9 +472,7 @@ int ShardComm::search_batch(const GpuFlatIndex* shard, const double* queries, ui
     const double local_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_local).count();
     SH_HIP_OR_ABORT(hipSetDevice(merger_.device()));
     if (prof) SH_HIP_OR_ABORT(hipEventRecord(ev_[0], merger_.stream()));
-    if (on_device)
-        SH_HIP_OR_ABORT(hipMemcpyAsync(merger_.d_send(), merger_.h_hdr(), SHARD_HDR_WORDS * 8, hipMemcpyHostToDevice, merger_.stream()));
-    else
+    if (!on_device)
         SH_HIP_OR_ABORT(hipMemcpyAsync(merger_.d_send(), merger_.h_send(), words * 8, hipMemcpyHostToDevice, merger_.stream()));
     if (prof) SH_HIP_OR_ABORT(hipEventRecord(ev_[1], merger_.stream()));
     // THE exchange step of the path: one all-gather of per-shard top-k records (config 3: 1024 queries x k 10
