@@ -633,6 +633,56 @@ def test_coalescing_is_on_by_default_and_a_lone_caller_takes_the_single_search_p
     assert off.coalesce_stats() == (0, 0)
 
 
+def test_adaptive_gather_changes_how_passes_fill_not_what_they_answer(V, O):
+    """vl_index_coalesce_gather: a lone caller never waits (estimates 1, 1); eight callers in a closed loop get the lone
+    answers with the gather on and off; with it on, leaders wait for their peers (counted) and the passes are fuller;
+    switching it off stops the waiting.  Flat and HNSW handles answer the same entry point."""
+    import threading
+    rng = np.random.default_rng(77)
+    n, dim, k = 300_000, 64, 10
+    rows = unit_rows(rng, n, dim)
+    gpu = V.FlatIndex(dim)
+    gpu.add_rows(np.arange(n, dtype=np.uint64), rows, validate=False)
+    Q = unit_rows(rng, 96, dim)
+    want = [gpu.search_arrays(Q[i], k, 0) for i in range(96)]
+    assert gpu.coalesce_gather() == (0, 0)               # 96 lone searches: nobody ever waited
+
+    def closed_loop():
+        errors = []
+        bar = threading.Barrier(8)
+
+        def worker(t):
+            try:
+                bar.wait()
+                for rep in range(6):
+                    for i in range(t, 96, 8):
+                        gi, gs = gpu.search_arrays(Q[i], k, 0)
+                        if gi.tolist() != want[i][0].tolist() or gs.tolist() != want[i][1].tolist():
+                            errors.append((t, i))
+            except Exception as e:  # pragma: no cover
+                errors.append((t, repr(e)))
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+        b0, q0 = gpu.coalesce_stats()
+        [x.start() for x in th]
+        [x.join() for x in th]
+        b1, q1 = gpu.coalesce_stats()
+        assert errors == [] and q1 - q0 == 6 * 96
+        return (q1 - q0) / (b1 - b0)
+
+    fill_on = closed_loop()
+    w_on, us_on = gpu.coalesce_gather()
+    assert w_on > 0 and us_on >= 0                        # leaders did wait for peers on their way back
+    assert gpu.coalesce_gather(False) == (w_on, us_on)   # the switch; the counters stay
+    fill_off = closed_loop()
+    assert gpu.coalesce_gather() == (w_on, us_on)         # off: nobody waits
+    assert fill_on > 1.0 and fill_off > 1.0               # passes were shared either way
+    gpu.coalesce_gather(True)
+    hn = V.HNSWIndex(dim, 0)
+    hn.add_rows(np.arange(5000, dtype=np.uint64), rows[:5000])
+    hn.search_arrays(Q[0], k, 0)
+    assert hn.coalesce_gather() == (0, 0) and hn.coalesce_gather(False) == (0, 0)
+
+
 def test_large_index_properties(V):
     """N = 2M x 128 (too big for the oracle in a test): fast path == exact path bit for bit,
     sortedness, idempotence, self-query returns the row itself with score 1, delete removes it."""
