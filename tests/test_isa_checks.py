@@ -90,8 +90,8 @@ def test_mfma_scan_default_shapes_do_not_spill(mfma_asm):
 def test_row_stationary_kernel_shapes_in_the_default_build(mfma_asm):
     """k_mfma_rows (K4r), the shipped batch filter: the default build holds ONLY the two-waves-per-SIMD shape (RBN 2, NW 8) --
     the one-wave-per-SIMD shape measured 8-28 % slower in round 4 and compiles in with -DRS_WIDE_SHAPES alone -- and its
-    pass-1 instantiations stay within the spills they are known to have (Euclidean at strides 384 / 512: 10 / 33 registers,
-    there since round 2; everything else none)."""
+    pass-1 instantiations stay within the spills they are known to have (Euclidean at stride 512: 25 registers -- 33 before
+    its per-query-block thresholds moved to LDS in round 4, which freed stride 384 of its 10; everything else none)."""
     asm = mfma_asm
     seen = 0
     for block in asm.split("- .agpr_count:")[1:]:
@@ -106,6 +106,6 @@ def test_row_stationary_kernel_shapes_in_the_default_build(mfma_asm):
         scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1))
         vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", block).group(1))
         assert vgpr <= 256, (name, vgpr)            # two waves per SIMD
-        allowed = 160 if (metric == 1 and ksteps in (24, 32) and mode == 1) else 0
+        allowed = 128 if (metric == 1 and ksteps == 32 and mode == 1) else 0
         assert scratch <= allowed, (name, scratch)
     assert seen == 45                                # 5 strides x 3 metrics x (sampling, pass 1, pass 1 with streaming loads)

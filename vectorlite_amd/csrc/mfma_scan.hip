@@ -592,6 +592,15 @@ void k_mfma_rows(const __bf16* __restrict__ slab16,
     // MODE 0: a workgroup reports gpw groups (1, 2, 4 or 8: its waves in equal shares), so that the sampling pass can run
     // on the same full-chip grid as pass 1 whatever the number of query chunks and still hand k_thresholds 64..256 groups
     __shared__ int gmax_lds[MODE == 0 ? NW * QPB : 1];
+    // Euclidean pass 1 with the whole K in registers (strides <= 512) is the one shape that did not fit 256 registers: the
+    // 8 per-query-block thresholds of a lane went to scratch and came back through 131-238 scratch loads per row block --
+    // on the SAME counter (vmcnt) as the row-fragment loads.  There they live in LDS instead: one ds_read_b32 per use.
+#ifdef RS_THR_LDS_OFF  // diagnostic build: the thresholds in registers everywhere, as before
+    constexpr bool THR_LDS = false;
+#else
+    constexpr bool THR_LDS = (MODE == 1 && METRIC == EUCLIDEAN && PH == 1 && RBN == 2);
+#endif
+    __shared__ float thr_lds[THR_LDS ? QPB : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -621,20 +630,26 @@ void k_mfma_rows(const __bf16* __restrict__ slab16,
         }
         if (MODE == 0)
             for (int c = tid; c < NW * QPB; c += NT) gmax_lds[c] = enc_f(-INFINITY);
+        if (THR_LDS)
+            for (int c = tid; c < QPB; c += NT) thr_lds[c] = (chunk_base + (uint32_t)c < nq) ? thr[chunk_base + (uint32_t)c] : INFINITY;
     }
     __syncthreads();
 
-    float thr_q[QB], run_max[QB];
+    float thr_q[THR_LDS ? 1 : QB], run_max[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const uint32_t qq = chunk_base + qb * 16 + c16;
-        thr_q[qb] = INFINITY;  // padding queries never pass
-        if (MODE == 1 && qq < nq) thr_q[qb] = thr[qq];
+        if (!THR_LDS) {
+            thr_q[qb] = INFINITY;  // padding queries never pass
+            if (MODE == 1 && qq < nq) thr_q[qb] = thr[qq];
 #ifdef RS_DBG_NOCAND
-        thr_q[qb] = INFINITY;  // diagnostic: nothing ever passes
+            thr_q[qb] = INFINITY;  // diagnostic: nothing ever passes
 #endif
+        }
         run_max[qb] = -INFINITY;
     }
+    // this lane's threshold for query block qb: a register, or (THR_LDS) one ds_read_b32 per use
+    auto thr_of = [&](int qb) -> float { return THR_LDS ? thr_lds[qb * 16 + c16] : thr_q[THR_LDS ? 0 : qb]; };
     uint32_t my_cnt = 0;
 
     // block schedule: neighbouring WORKGROUPS stream neighbouring BR-row blocks (block = begin + x + gridDim.x * (wave + NW i)),
@@ -873,7 +888,7 @@ void k_mfma_rows(const __bf16* __restrict__ slab16,
                 // threshold?  (m - T >= 0; T = +inf for padding queries gives -inf, a fully masked block gives -inf or NaN)
                 float ex[HQB];
 #pragma unroll
-                for (int j = 0; j < HQB; ++j) ex[j] = mj[j] - thr_q[half * HQB + j];
+                for (int j = 0; j < HQB; ++j) ex[j] = mj[j] - thr_of(half * HQB + j);
                 float any = ex[0];
 #pragma unroll
                 for (int j = 1; j + 1 < HQB; j += 2) any = max3f(any, ex[j], ex[j + 1]);
@@ -883,7 +898,7 @@ void k_mfma_rows(const __bf16* __restrict__ slab16,
 #pragma unroll
                 for (int j = 0; j < HQB; ++j) {
                     const int qb = half * HQB + j;
-                    const float tq = thr_q[qb];
+                    const float tq = thr_of(qb);
                     if (__builtin_amdgcn_ballot_w64(mj[j] >= tq) == 0ull) continue;  // wave-uniform
 #pragma unroll
                     for (int rb = 0; rb < RBN; ++rb) {
