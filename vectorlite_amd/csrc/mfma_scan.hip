@@ -595,8 +595,10 @@ void k_mfma_rows(const __bf16* __restrict__ slab16,
     // Euclidean pass 1 with the whole K in registers (strides <= 512) is the one shape that did not fit 256 registers: the
     // 8 per-query-block thresholds of a lane went to scratch and came back through 131-238 scratch loads per row block --
     // on the SAME counter (vmcnt) as the row-fragment loads.  There they live in LDS instead: one ds_read_b32 per use.
-#ifdef RS_THR_LDS_OFF  // diagnostic build: the thresholds in registers everywhere, as before
+#if defined(RS_THR_LDS_OFF)  // diagnostic build: the thresholds in registers everywhere, as before
     constexpr bool THR_LDS = false;
+#elif defined(RS_THR_LDS_ALL)  // diagnostic build: in LDS for every metric and stride
+    constexpr bool THR_LDS = (MODE == 1 && RBN == 2);
 #else
     constexpr bool THR_LDS = (MODE == 1 && METRIC == EUCLIDEAN && PH == 1 && RBN == 2);
 #endif
