@@ -56,6 +56,14 @@ static int adaptive_gather()
                 (unsigned long long)w_lone);
     if (w_off != 0 || w_lone != 0 || p_lone != 25) return 13;  // no waiting when it is off, none for a lone caller
     if (p_on > 34) return 14;                                  // ~25 passes of 8 (a few smaller ones while it settles)
+    // many callers on few cores: arrivals wake the gathering leader only, so 200 callers x 6 rounds of 2 ms passes finish in
+    // about 6 passes' time (a wake-up of every sleeper per arrival used to take tens of milliseconds per pass)
+    uint64_t p_many = 0, w_many = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (closed_loop(true, 200, 6, &p_many, &w_many)) return 15;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("200 callers x 6 rounds: %llu passes, %.1f ms\n", (unsigned long long)p_many, ms);
+    if (p_many > 30 || ms > 400.0) return 16;
     return 0;
 }
 

@@ -57,7 +57,9 @@ public:
         const size_t max_batch = (size_t)(max_.load() < 2 ? 2 : max_.load());
         std::unique_lock<std::mutex> lk(mu_);
         q_.push_back(&r);
-        cv_.notify_all();  // a leader waiting in its window counts arrivals
+        // a leader waiting in its window / gather counts arrivals: it alone listens on cv_arrive_ (waking every sleeping
+        // follower for every arrival was a T^2 storm of wake-ups on one mutex: 256 callers took 35 ms per pass)
+        if (gathering_) cv_arrive_.notify_one();
         while (!r.done) {
             if (leader_) {
                 cv_.wait(lk);
@@ -65,8 +67,9 @@ public:
             }
             leader_ = true;
             const int window = window_us_.load();
+            gathering_ = true;
             if (window > 0 && q_.size() < max_batch)
-                cv_.wait_for(lk, std::chrono::microseconds(window), [&] { return q_.size() >= max_batch; });
+                cv_arrive_.wait_for(lk, std::chrono::microseconds(window), [&] { return q_.size() >= max_batch; });
             else if (window == 0 && adaptive_.load(std::memory_order_relaxed)) {
                 const size_t peers = std::min(max_batch, std::max(hist_[0], hist_[1]));
                 const int64_t cap = std::min<int64_t>(pass_us_ / 4, 400);
@@ -78,12 +81,13 @@ public:
                 };
                 if (cap > 0 && !gathered()) {
                     const auto t0 = std::chrono::steady_clock::now();
-                    cv_.wait_for(lk, std::chrono::microseconds(cap), gathered);
+                    cv_arrive_.wait_for(lk, std::chrono::microseconds(cap), gathered);
                     waits_.fetch_add(1);
                     waited_us_.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(
                                              std::chrono::steady_clock::now() - t0).count());
                 }
             }
+            gathering_ = false;
             std::vector<Req*> batch;
             batch.push_back(&r);
             for (auto it = q_.begin(); it != q_.end();) {
@@ -137,9 +141,11 @@ public:
 
 private:
     std::mutex mu_;
-    std::condition_variable cv_;
+    std::condition_variable cv_;         // followers: "my request is done" / "the leader slot is free"
+    std::condition_variable cv_arrive_;  // the gathering leader: "somebody queued up"
     std::deque<Req*> q_;
     bool leader_ = false;
+    bool gathering_ = false;             // the leader is waiting for arrivals (under mu_)
     size_t hist_[2] = {0, 0};  // callers in the loop as the last two passes saw them: answered + queued behind (under mu_)
     int64_t pass_us_ = 0;      // recent pass time, exponentially averaged (under mu_)
     std::atomic<bool> adaptive_{adaptive_default()};
