@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--threads", default="16,64")
     ap.add_argument("--per-thread", type=int, default=60)
+    ap.add_argument("--index", default="flat", choices=["flat", "hnsw"], help="hnsw: config 4's index (latent-16 rows, default profile), strict beam")
     a = ap.parse_args()
     so = os.path.join(tempfile.mkdtemp(), "native_loadgen.so")
     subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-pthread", "-o", so, os.path.join(ROOT, "tools", "native_loadgen.c")], check=True)
@@ -27,26 +28,42 @@ def main():
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
     g.manual_seed(7)
-    idx = V.FlatIndex(a.dim)
-    idx.reserve(a.rows)
+    hnsw = a.index == "hnsw"
+    idx = V.HNSWIndex(a.dim, 0) if hnsw else V.FlatIndex(a.dim)
+    if not hnsw:
+        idx.reserve(a.rows)
+    A = torch.randn((16, a.dim), dtype=torch.float64, device=dev, generator=g)
+
+    def gen(c):
+        if hnsw:  # rows = A z + 0.05 noise, z in R^16: bench.py's latent-16 corpus
+            x = torch.randn((c, 16), dtype=torch.float64, device=dev, generator=g) @ A
+            x += 0.05 * torch.randn((c, a.dim), dtype=torch.float64, device=dev, generator=g)
+        else:
+            x = torch.randn((c, a.dim), dtype=torch.float64, device=dev, generator=g)
+        return x / torch.linalg.vector_norm(x, dim=1, keepdim=True)
     done = 0
     while done < a.rows:
-        c = min(500_000, a.rows - done)
-        x = torch.randn((c, a.dim), dtype=torch.float64, device=dev, generator=g)
-        x /= torch.linalg.vector_norm(x, dim=1, keepdim=True)
-        idx.add_rows(np.arange(done, done + c, dtype=np.uint64), x, validate=False)
+        c = min(250_000 if hnsw else 500_000, a.rows - done)
+        x = gen(c)
+        if hnsw:
+            idx.add_rows(np.arange(done, done + c, dtype=np.uint64), x)
+        else:
+            idx.add_rows(np.arange(done, done + c, dtype=np.uint64), x, validate=False)
         done += c
         del x
     k = 10
     fn = C.cast(L.vl_index_search_cap, C.c_void_p)
     for T in [int(t) for t in a.threads.split(",")]:
         per = a.per_thread
-        Q = np.random.default_rng(11 + T).standard_normal((T * per, a.dim))
-        Q /= np.linalg.norm(Q, axis=1, keepdims=True)
-        Q = np.ascontiguousarray(Q)
+        if hnsw:
+            Q = np.ascontiguousarray(gen(T * per).cpu().numpy())
+        else:
+            Q = np.random.default_rng(11 + T).standard_normal((T * per, a.dim))
+            Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+            Q = np.ascontiguousarray(Q)
         lone = [idx.search_arrays(Q[t * per], k, 0) for t in range(T)]
-        idx.search_batch(Q[:16], k, 0)      # the bf16 copy of the rows exists before anything is timed
-        out = {"threads": T, "queries": T * per, "rows": a.rows, "dim": a.dim}
+        idx.search_batch(Q[:16], k, 0)      # (flat: the bf16 copy of the rows exists before anything is timed)
+        out = {"index": a.index, "threads": T, "queries": T * per, "rows": a.rows, "dim": a.dim}
         for label, adaptive in (("settle", True), ("adaptive_gather", True), ("window0_without_gather", False)):
             idx.coalesce_gather(adaptive)
             b0, q0 = idx.coalesce_stats()

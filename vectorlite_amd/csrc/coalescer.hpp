@@ -13,6 +13,7 @@
 // and a leader that finds fewer compatible requests queued than the larger of the last two estimates waits for them
 // (they are all either queued or on their way back, since only one pass is in flight), but never longer than a quarter
 // of the recent pass time, and never more than 400 us.  A lone caller's estimates are (1, 1): target 1, no wait.
+// And only while waiting pays: requests must arrive faster during a gather than going at once would answer them (run()).
 #pragma once
 
 #include <algorithm>
@@ -59,7 +60,7 @@ public:
         q_.push_back(&r);
         // a leader waiting in its window / gather counts arrivals: it alone listens on cv_arrive_ (waking every sleeping
         // follower for every arrival was a T^2 storm of wake-ups on one mutex: 256 callers took 35 ms per pass)
-        if (gathering_) cv_arrive_.notify_one();
+        if (gathering_ && q_.size() >= gather_target_) cv_arrive_.notify_one();  // not before: the leader sleeps until its target is there (or its time is up)
         while (!r.done) {
             if (leader_) {
                 cv_.wait(lk);
@@ -68,23 +69,36 @@ public:
             leader_ = true;
             const int window = window_us_.load();
             gathering_ = true;
+            gather_target_ = max_batch;
             if (window > 0 && q_.size() < max_batch)
                 cv_arrive_.wait_for(lk, std::chrono::microseconds(window), [&] { return q_.size() >= max_batch; });
             else if (window == 0 && adaptive_.load(std::memory_order_relaxed)) {
                 const size_t peers = std::min(max_batch, std::max(hist_[0], hist_[1]));
                 const int64_t cap = std::min<int64_t>(pass_us_ / 4, 400);
-                auto gathered = [&] {
-                    if (q_.size() < peers) return false;
+                auto compatible = [&] {
                     size_t n = 0;
                     for (Req* o : q_) n += (o == &r || same(r, *o)) ? 1 : 0;
-                    return n >= peers;
+                    return n;
                 };
-                if (cap > 0 && !gathered()) {
+                auto gathered = [&] { return q_.size() >= peers && compatible() >= peers; };
+                const size_t n0 = compatible();
+                // Is waiting worth it?  Going now answers n0 requests per pass time; waiting pays while requests arrive FASTER
+                // than that (the rate the last gathers saw).  Few callers on an idle queue: n0 = 1, peers arrive within
+                // microseconds -> wait.  Many more callers than cores: a long queue is there already and the peers are stuck
+                // in the OS run queue -> go (256 threads on an HNSW handle: 123 k QPS waiting, 223 k not).  Every 16th
+                // such pass waits anyway and measures again.
+                const bool worth = arr_rate_ < 0.0 || arr_rate_ * (double)pass_us_ > (double)n0 || (++probe_ % 16u) == 0u;
+                if (cap > 0 && n0 < peers && worth) {
+                    // the more of the peers are here already, the less there is to wait for: the cap shrinks with the share missing
+                    const int64_t cap_now = std::max<int64_t>(1, cap * (int64_t)(peers - n0) / (int64_t)peers);
                     const auto t0 = std::chrono::steady_clock::now();
-                    cv_arrive_.wait_for(lk, std::chrono::microseconds(cap), gathered);
+                    gather_target_ = peers;
+                    cv_arrive_.wait_for(lk, std::chrono::microseconds(cap_now), gathered);
+                    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                    const double rate = (double)(compatible() - n0) / (us > 1.0 ? us : 1.0);
+                    arr_rate_ = arr_rate_ < 0.0 ? rate : 0.5 * (arr_rate_ + rate);
                     waits_.fetch_add(1);
-                    waited_us_.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(
-                                             std::chrono::steady_clock::now() - t0).count());
+                    waited_us_.fetch_add((uint64_t)us);
                 }
             }
             gathering_ = false;
@@ -146,8 +160,11 @@ private:
     std::deque<Req*> q_;
     bool leader_ = false;
     bool gathering_ = false;             // the leader is waiting for arrivals (under mu_)
+    size_t gather_target_ = 0;           // ... for this many queued requests (under mu_)
     size_t hist_[2] = {0, 0};  // callers in the loop as the last two passes saw them: answered + queued behind (under mu_)
     int64_t pass_us_ = 0;      // recent pass time, exponentially averaged (under mu_)
+    double arr_rate_ = -1.0;   // requests per microsecond that arrived while the last gathers waited; < 0: not measured yet (under mu_)
+    uint32_t probe_ = 0;       // passes that skipped the gather since the last measurement (under mu_)
     std::atomic<bool> adaptive_{adaptive_default()};
     std::atomic<int> max_{0}, window_us_{0};
     std::atomic<uint64_t> batches_{0}, queries_{0}, waits_{0}, waited_us_{0};
