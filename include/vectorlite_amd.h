@@ -402,7 +402,10 @@ int vl_index_set_single_filter(vl_index *h, int mode);
  * off): N callers in a closed loop otherwise fall into passes of 1 and N - 1 in turn (the first caller back leads at
  * once, alone).  Every pass leaves an estimate of the callers in the loop (requests answered + compatible requests queued
  * behind it); a leader that finds fewer queued than the larger of the last two estimates waits for them, at most a quarter
- * of the recent pass time and never more than 400 us; a lone caller (estimates 1, 1) never waits.
+ * of the recent pass time and never more than 400 us -- and only while requests arrive faster during a gather than going
+ * at once would answer them (many more threads than cores: the peers sit in the run queue, the leader goes); a lone
+ * caller (estimates 1, 1) never waits.  Native threads on one 10 M x 384 index: 16 -> 11.5 k QPS at 1.39 ms, 64 -> 39 k,
+ * 256 -> 67 k (tools/concurrent_native.py).
  * vl_index_coalesce_gather: adaptive = 1 / 0 sets the switch, -1 leaves it; waits / waited_us (may be NULL) report the
  * passes whose leader waited and the microseconds spent waiting since creation. */
 int vl_index_set_coalescing(vl_index *h, int max_batch, int window_us);
