@@ -1308,8 +1308,53 @@ def run_rank(args) -> int:
         idx.coalesce_gather(False)
         r_off = closed_loop()
         idx.coalesce_gather(True)
+
+        def native_threads():
+            """The same loop from NATIVE threads (tools/native_loadgen.c: pthreads on vl_index_search_cap): no GIL between a
+            caller's return and its next call -- what a Rust or C server's workers do."""
+            import ctypes as C
+            import subprocess
+            import tempfile
+            from vectorlite_amd import _lib
+            so = os.path.join(tempfile.mkdtemp(), "native_loadgen.so")
+            subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-pthread", "-o", so, os.path.join(ROOT, "tools", "native_loadgen.c")],
+                           check=True, capture_output=True, timeout=60)
+            G = C.CDLL(so)
+            fn = C.cast(_lib.load().vl_index_search_cap, C.c_void_p)
+            Qn = np.ascontiguousarray(Qt)
+            res = {}
+            for label, adaptive in (("settle", True), ("value", True), ("without_adaptive_gather", False)):
+                idx.coalesce_gather(adaptive)
+                lat = np.zeros(T * per)
+                fid = np.zeros(T * k, dtype=np.uint64)
+                fsc = np.zeros(T * k)
+                el = C.c_double(0.0)
+                b0, q0 = idx.coalesce_stats()
+                rc = G.vl_loadgen(fn, idx._h, Qn.ctypes.data_as(C.c_void_p), C.c_uint64(dim), C.c_uint64(k), C.c_int(int(metric)),
+                                  C.c_int(T), C.c_int(per), lat.ctypes.data_as(C.c_void_p), fid.ctypes.data_as(C.c_void_p),
+                                  fsc.ctypes.data_as(C.c_void_p), C.byref(el))
+                b1, q1 = idx.coalesce_stats()
+                if rc != 0:
+                    raise RuntimeError(f"vl_index_search_cap returned {rc} under the native load generator")
+                same = sum(int(fid[t * k:(t + 1) * k].tolist() == lone[t][0].tolist() and fsc[t * k:(t + 1) * k].tolist() == lone[t][1].tolist())
+                           for t in range(T))
+                la = np.sort(lat) * 1e3
+                if label != "settle":
+                    res[label] = {"value": round(T * per / el.value, 1), "unit": "queries/s",
+                                  "latency_ms": {"mean": round(float(la.mean()), 3), "p50": round(float(la[len(la) // 2]), 3),
+                                                 "p99": round(float(la[int(len(la) * 0.99)]), 3)},
+                                  "queries_per_pass": round((q1 - q0) / max(b1 - b0, 1), 2), "identical_to_lone_search": f"{same}/{T}"}
+            idx.coalesce_gather(True)
+            return dict(res["value"], without_adaptive_gather=res["without_adaptive_gather"],
+                        note="pthreads in a closed loop on vl_index_search_cap (tools/native_loadgen.c), same handle, same queries")
+        try:
+            r_native = native_threads()
+        except Exception as e:  # no compiler on the box, ...: the Python-thread figures above stand on their own
+            idx.coalesce_gather(True)
+            r_native = {"skipped": repr(e)[:200]}
         out["concurrent_16_threads"] = {
             "threads": T, "queries": T * per, **r_on,
+            "native_threads": r_native,
             "handle": "as created: coalescing on by default (max 256 per pass, window 0, adaptive gather); lone callers are the timed region above",
             "without_adaptive_gather": r_off,
             "note": "concurrent callers share slab passes (bf16 MFMA filter + exact f64 finalize): every answer is the lone search's; "

@@ -81,6 +81,8 @@ def test_bench_child_process_prints_the_whole_contract_line(steps, warmup):
     cc = out["concurrent_16_threads"]
     assert cc["threads"] == 16 and cc["identical_to_lone_search"] == "16/16" and cc["value"] > 0
     assert cc["passes"] <= cc["queries"] and cc["latency_ms"]["p99"] >= cc["latency_ms"]["p50"] > 0
+    nt = cc["native_threads"]                  # the same loop from pthreads (no GIL between a return and the next call)
+    assert "skipped" in nt or (nt["identical_to_lone_search"] == "16/16" and nt["value"] > 0 and nt["without_adaptive_gather"]["value"] > 0)
     off = cc["without_adaptive_gather"]        # the same loop with the leader's gather off: window 0 as rounds 1-3 ran it
     assert off["identical_to_lone_search"] == "16/16" and off["leader_waits"] == 0 and off["value"] > 0
     c4 = oc["c4_hnsw"]
